@@ -1,0 +1,179 @@
+/*
+ * otter_hip.h — C ABI of libotter_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for OTTeR's dense-retrieval hot path.  The reference has no
+ * FFI of its own: its boundary is two Python call surfaces.
+ * Each entry point below cites the reference call it replaces
+ * (paths relative to the reference tree).
+ *
+ *   index   : faiss.IndexFlatIP(d) / .add(xb) / .search(q, k)
+ *             scripts/eval_ottqa_retrieval.py:108-109,129
+ *   encoder : model = Cls(config, args); load_saved(...); model(batch)['embed']
+ *             scripts/encode_corpus.py:54-68,98,139-144
+ *             retrieval/models/tb_retriever.py:150-261, retrieval/models/retriever.py:249-345
+ *
+ * Conventions
+ *   - every function returns int: 0 = OK, negative = error class below; the
+ *     message is kept per thread and read with otter_last_error().
+ *   - the caller owns every buffer passed in or out; an index owns its private
+ *     HBM copy of the corpus; an encoder owns its private HBM copy of the weights.
+ *   - handles are not thread-safe; one handle per device.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the device's default
+ *     stream).  Calls with host buffers synchronise the stream before returning;
+ *     calls with device buffers only enqueue work.
+ *   - no torch types anywhere; plain pointers and sizes only.
+ */
+#ifndef OTTER_HIP_H
+#define OTTER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error classes */
+#define OTTER_OK        0
+#define OTTER_EINVAL   (-1)   /* bad argument (shape, k, dtype, NULL)            */
+#define OTTER_ENOMEM   (-2)   /* hipMalloc failed                                */
+#define OTTER_EHIP     (-3)   /* any other HIP runtime error                     */
+#define OTTER_ESTATE   (-4)   /* call not valid in the handle's current state    */
+#define OTTER_ENOTIMPL (-5)   /* configuration not built into this library       */
+
+/* element types */
+#define OTTER_F32   0
+#define OTTER_BF16  1
+#define OTTER_F16   2
+#define OTTER_I64   3
+
+/* largest k the fused scan keeps per query (same bound as faiss' GPU k-select) */
+#define OTTER_MAX_K 2048
+
+const char* otter_last_error(void);
+/* library ABI version (bumped on any signature change) */
+int otter_version(void);
+/* number of visible HIP devices, or a negative error class */
+int otter_device_count(void);
+
+/* ------------------------------------------------------------------ index */
+
+typedef struct otter_index otter_index;
+
+/* faiss.IndexFlatIP(d)  — scripts/eval_ottqa_retrieval.py:108.
+ * dtype = storage type of the corpus in HBM (OTTER_F32: exact IndexFlatIP
+ * arithmetic in fp32).  The index lives on HIP device `device`. */
+int otter_index_create(int d, int dtype, int device, otter_index** out);
+
+/* index.add(xb) — scripts/eval_ottqa_retrieval.py:109.
+ * x: float32 row-major [n, d], host (x_is_device = 0) or device pointer.
+ * ids are insertion order, continuing from ntotal. */
+int otter_index_add(otter_index* ix, const void* x, int64_t n, int x_is_device, void* stream);
+
+/* D, I = index.search(q, k) — scripts/eval_ottqa_retrieval.py:129.
+ * q: float32 [nq, d]; D: float32 [nq, k]; I: int64 [nq, k]; all three host
+ * (io_is_device = 0) or all three device pointers.  Rows are sorted by
+ * (score descending, id ascending); when fewer than k rows exist the tail is
+ * I = -1, D = -FLT_MAX (faiss convention; the reference guards for it at
+ * retrieval/eval_ottqa_retrieval_tfidffilter.py:282-284). 1 <= k <= OTTER_MAX_K. */
+int otter_index_search(otter_index* ix, const void* q, int64_t nq, int k,
+                       float* D, int64_t* I, int io_is_device, void* stream);
+
+/* index.ntotal / index.d */
+int64_t otter_index_ntotal(const otter_index* ix);
+int     otter_index_d(const otter_index* ix);
+
+/* index.reset(): drop all rows, keep the allocation */
+int otter_index_reset(otter_index* ix);
+
+/* Row-sharded use (replaces faiss.index_cpu_to_all_gpus,
+ * scripts/eval_ottqa_retrieval.py:110-112): ids reported by search() become
+ * id_base + local row, so that per-shard results carry global ids. */
+int otter_index_set_id_base(otter_index* ix, int64_t id_base);
+
+void otter_index_destroy(otter_index* ix);
+
+/* Final merge of the row-sharded search: G sorted candidate lists per query
+ * (Dc float32 [G, nq, k], Ic int64 [G, nq, k], device pointers, as returned
+ * by G per-shard search() calls and exchanged with an all-gather) are merged
+ * into D [nq, k], I [nq, k] (device) under the same (score desc, id asc)
+ * order; entries with id < 0 are padding.  G * k <= 8192 (merge hierarchically
+ * beyond that: the output has the layout of one input list). */
+int otter_merge_topk(int device, const float* Dc, const int64_t* Ic, int G, int64_t nq, int k,
+                     float* D, int64_t* I, void* stream);
+
+/* ---------------------------------------------------------------- encoder */
+
+typedef struct otter_encoder otter_encoder;
+
+/* pooling_masked_part methods — retrieval/models/tb_retriever.py:42-58 */
+#define OTTER_POOL_MEAN  0
+#define OTTER_POOL_SUM   1
+#define OTTER_POOL_MAX   2
+#define OTTER_POOL_CLS   3
+#define OTTER_POOL_FIRST 4
+
+/* position-id conventions of the HF embedding layer */
+#define OTTER_POS_BERT    0   /* position = arange(L)                                   */
+#define OTTER_POS_ROBERTA 1   /* position = cumsum(ids != pad) * (ids != pad) + pad_id  */
+
+typedef struct otter_encoder_cfg {
+    int32_t vocab_size;
+    int32_t hidden_size;              /* 768 */
+    int32_t num_hidden_layers;        /* 12  */
+    int32_t num_attention_heads;      /* 12  */
+    int32_t intermediate_size;        /* 3072 */
+    int32_t max_position_embeddings;  /* 514 roberta / 512 bert */
+    int32_t type_vocab_size;          /* 1 roberta / 2 bert */
+    int32_t pad_token_id;             /* 1 roberta / 0 bert */
+    int32_t position_mode;            /* OTTER_POS_* */
+    int32_t three_cat;                /* 1: [B, 3H] (tb_retriever.py), 0: [B, H] (retriever.py) */
+    int32_t no_proj;                  /* 1: part1 = h[:,0]; 0: part1 = LN(Linear(h[:,0])) */
+    int32_t part_pooling;             /* OTTER_POOL_* for part2/part3 */
+    float   layer_norm_eps;           /* 1e-5 roberta / 1e-12 bert */
+} otter_encoder_cfg;
+
+/* model = Cls(bert_config, args) — scripts/encode_corpus.py:54-68 */
+int otter_encoder_create(const otter_encoder_cfg* cfg, int device, otter_encoder** out);
+
+/* load_saved(model, ckpt, exact=False) — retrieval/utils/utils.py:12-28.
+ * name is the state_dict key without the leading "encoder." of the wrapper
+ * (e.g. "embeddings.word_embeddings.weight", "encoder.layer.0.attention.self.query.weight",
+ * "project.0.weight"); host_ptr is float32 row-major of the given shape.
+ * Returns OTTER_EINVAL for an unknown name or a wrong shape. */
+int otter_encoder_set_weight(otter_encoder* enc, const char* name, const float* host_ptr,
+                             const int64_t* shape, int ndim);
+
+/* model.to(device); model.eval() — scripts/encode_corpus.py:99,130.
+ * Checks that every tensor was set and repacks the weights for the compute
+ * type: OTTER_F32 (parity path) or OTTER_BF16 (throughput path, fp32 accumulate). */
+int otter_encoder_finalize(otter_encoder* enc, int compute_dtype);
+
+/* out = model(batch)['embed'] — retrieval/models/tb_retriever.py:256-261,172-195;
+ * retrieval/models/retriever.py:340-345,270-286.
+ * All inputs are device pointers to int64 [B, L] (the reference batch dict of
+ * retrieval/data/encode_datasets.py:393-417); type_ids/part2_mask/part3_mask
+ * may be NULL (type 0 / masks required only when three_cat = 1).
+ * out: device float32 [B, D], D = 3H when three_cat else H. */
+int otter_encoder_forward(otter_encoder* enc,
+                          const int64_t* input_ids, const int64_t* input_mask,
+                          const int64_t* type_ids, const int64_t* part2_mask,
+                          const int64_t* part3_mask, int B, int L,
+                          float* out, void* stream);
+
+/* Parity hook (no counterpart call in the reference; it exposes what HF's
+ * AutoModel returns as hidden_states[n_layers], tb_retriever.py:180-185):
+ * runs the embedding layer and the first n_layers transformer layers
+ * (0 <= n_layers <= num_hidden_layers) and writes the hidden state,
+ * device float32 [B, L, H]. */
+int otter_encoder_forward_hidden(otter_encoder* enc,
+                                 const int64_t* input_ids, const int64_t* input_mask,
+                                 const int64_t* type_ids, int B, int L, int n_layers,
+                                 float* hidden, void* stream);
+
+int  otter_encoder_out_dim(const otter_encoder* enc);
+void otter_encoder_destroy(otter_encoder* enc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OTTER_HIP_H */

@@ -1,0 +1,799 @@
+// index.hip — exact inner-product top-k over a row-major fp32 corpus in HBM (gfx950).
+//
+// Replaces faiss.IndexFlatIP add()/search() as the reference calls them
+// (scripts/eval_ottqa_retrieval.py:108-109,129).  The N x Q score matrix is never
+// written: one kernel streams corpus rows through LDS (LDS-DMA ring), multiplies
+// them with a resident tile of queries on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32, exact fp32 fma chain) and filters every score against a
+// per-query running threshold; survivors go to a small per-(strip, query)
+// candidate buffer that is compacted by a wavefront radix select whenever it fills.
+// A second, tiny kernel bitonic-sorts the per-strip survivors of each query.
+//
+// Data layout
+//   corpus   X  [N][ld]   fp32, ld = d rounded up to 64 (zero padded), row i = id i
+//   queries  Qp [nq_pad][ld] fp32, zero padded to a multiple of the query tile
+//   cand     [S][nq_pad][CAP] u64 composite = key32(score) << 32 | (0xFFFFFFFF - row)
+//            (larger composite == ranks earlier: score desc, id asc; composites are unique)
+//   cnt      [S][nq_pad] u32 number of valid composites
+#include <float.h>
+
+#include <algorithm>
+#include <new>
+
+#include "otter_common.h"
+
+namespace {
+
+using namespace otter;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
+typedef uint32_t u32;
+
+#define AS1 __attribute__((address_space(1)))
+#define AS3 __attribute__((address_space(3)))
+
+constexpr int BK = 64;            // floats of k per LDS stage (256 B per row)
+constexpr int ROW_BYTES = BK * 4;  // 256
+constexpr int NTHREADS = 256;      // 4 waves, one per SIMD
+
+// monotone map float -> u32 (larger float <=> larger key); -0 is folded into +0
+__device__ __forceinline__ u32 f2key(float s) {
+    s = s + 0.0f;
+    u32 u = __float_as_uint(s);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float key2f(u32 k) {
+    u32 u = k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+    return __uint_as_float(u);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS [lds_dst, lds_dst + 1 KiB).
+// Issued from inline asm on purpose: hipcc then neither counts it nor guards later LDS
+// accesses with vmcnt(0); the kernel orders it by hand (counted vmcnt + barrier).
+__device__ __forceinline__ void dma16(const void* gsrc, u32 lds_dst) {
+    u32 keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+// workgroup barrier that does NOT drain the vector-memory queue (LDS-DMA stays in flight)
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+struct ScanArgs {
+    const float* X;     // [n][ld]
+    const float* Q;     // [nq_pad][ld]
+    u64* cand;          // [S][nq_pad][CAP]
+    u32* cnt;           // [S][nq_pad]
+    long long n;        // corpus rows
+    int ld;             // padded row length (floats), multiple of 64
+    int nq;             // real queries
+    int nq_pad;         // multiple of BQ
+    int k;
+    int qtiles;         // nq_pad / BQ
+    int strips;         // S
+    int total_tiles;    // ceil(n / BM)
+};
+
+// One wavefront selects the k largest of the n (<= 64*EPL) composites at `base`,
+// moves them to base[0..k) and returns the k-th largest.  Radix select, one bit
+// per round, counted with ballots; composites are unique so exactly k survive.
+template <int EPL>
+__device__ __forceinline__ u64 wave_compact(u64* base, int n, int k, int lane) {
+    u64 x[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        int idx = e * 64 + lane;
+        // agent-scope load: bypass this CU's vector L1 (entries were stored by other waves)
+        x[e] = idx < n ? __hip_atomic_load(base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    }
+    u64 T = 0;
+    for (int b = 63; b >= 0; --b) {
+        const u64 c = T | (1ull << b);
+        int cntv = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) cntv += __popcll(__ballot(x[e] >= c));
+        if (cntv >= k) T = c;
+    }
+    int off = 0;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const bool keep = x[e] >= T;
+        const u64 m = __ballot(keep);
+        const int pos = off + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0));
+        if (keep) base[pos] = x[e];
+        off += __popcll(m);
+    }
+    return T;
+}
+
+// WM x WQ waves; each wave owns (MB*32) corpus rows x (QB*32) queries of the tile.
+template <int WM, int WQ, int MB, int QB, int NSTAGE, int EPL>
+__global__ __launch_bounds__(NTHREADS, 1) void scan_kernel(ScanArgs a) {
+    static_assert(WM * WQ == 4, "4 waves per workgroup");
+    constexpr int BM = WM * MB * 32;
+    constexpr int BQ = WQ * QB * 32;
+    constexpr int CAP = EPL * 64;
+    constexpr int A_BYTES = BM * ROW_BYTES;
+    constexpr int B_BYTES = BQ * ROW_BYTES;
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_INSTR = BM / 16;  // LDS-DMA instructions per wave per stage (1 KiB = 4 rows each)
+    constexpr int B_INSTR = BQ / 16;
+    constexpr int IPS = A_INSTR + B_INSTR;
+    static_assert(CAP - BM >= 128, "candidate buffer too small");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32* sCnt = reinterpret_cast<u32*>(smem + NSTAGE * STAGE_BYTES);
+    u32* sThr = sCnt + BQ;
+    u32* sFlag = sThr + BQ;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WQ;
+    const int wq = wave % WQ;
+
+    const int qt = blockIdx.x % a.qtiles;
+    const int strip = blockIdx.x / a.qtiles;
+    const int q0 = qt * BQ;
+    const int t0 = (int)(((long long)strip * a.total_tiles) / a.strips);
+    const int t1 = (int)(((long long)(strip + 1) * a.total_tiles) / a.strips);
+    const int KS = a.ld / BK;
+
+    for (int i = tid; i < BQ; i += NTHREADS) {
+        sCnt[i] = 0;
+        sThr[i] = (q0 + i < a.nq) ? 0u : 0xFFFFFFFFu;  // padded queries never accept
+    }
+    if (tid == 0) *sFlag = 0;
+
+    u64* candBase = a.cand + ((size_t)strip * a.nq_pad + q0) * CAP;
+
+    // ---- LDS-DMA producer: one k-stage of one tile into ring slot `slot` ----
+    // LDS image of a stage: [row][16 chunks of 16 B]; chunk p of row r holds the
+    // global chunk p ^ (r & 15) (swizzle on the SOURCE address; the DMA writes linearly).
+    const int dma_r = lane >> 4;   // row within the 4-row group of one instruction
+    const int dma_p = lane & 15;   // LDS chunk position
+    const u32 lds0 = (u32)(uintptr_t)(AS3 char*)smem;
+    auto issue_stage = [&](int tile, int ks, int slot) {
+        const u32 sA = lds0 + slot * STAGE_BYTES;
+        const u32 sB = sA + A_BYTES;
+        const long long row0 = (long long)tile * BM;
+#pragma unroll
+        for (int ii = 0; ii < A_INSTR; ++ii) {
+            const int i = ii * 4 + wave;
+            const int r = 4 * i + dma_r;
+            long long grow = row0 + r;
+            grow = grow < a.n ? grow : a.n - 1;
+            const float* src = a.X + (size_t)grow * a.ld + ks * BK + ((dma_p ^ (r & 15)) << 2);
+            dma16(src, sA + i * 1024);
+        }
+#pragma unroll
+        for (int ii = 0; ii < B_INSTR; ++ii) {
+            const int i = ii * 4 + wave;
+            const int r = 4 * i + dma_r;
+            const float* src = a.Q + (size_t)(q0 + r) * a.ld + ks * BK + ((dma_p ^ (r & 15)) << 2);
+            dma16(src, sB + i * 1024);
+        }
+    };
+
+    int it_tile = t0, it_ks = 0;
+    auto issue_next = [&](int slot) {
+        if (it_tile < t1) {
+            issue_stage(it_tile, it_ks, slot);
+            if (++it_ks == KS) { it_ks = 0; ++it_tile; }
+        }
+    };
+
+    f32x16 acc[MB][QB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int q = 0; q < QB; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.0f;
+
+    // rare path: compact every over-full candidate buffer of this workgroup
+    auto compact_pass = [&](bool final_pass) {
+        wait_vmcnt<0>();  // own candidate stores have reached L2
+        wg_barrier();
+        for (int q = wave; q < BQ; q += 4) {
+            const int n = (int)sCnt[q];
+            const bool need = final_pass ? (n > a.k) : (n > CAP - BM);
+            if (need) {
+                const u64 T = wave_compact<EPL>(candBase + (size_t)q * CAP, n, a.k, lane);
+                if (lane == 0) {
+                    sCnt[q] = (u32)a.k;
+                    sThr[q] = (u32)(T >> 32);
+                }
+            }
+        }
+        if (tid == 0) *sFlag = 0;
+        wait_vmcnt<0>();
+        wg_barrier();
+    };
+
+    const long long total_stages = (long long)(t1 - t0) * KS;
+    long long f = 0;
+
+    // prologue: fill NSTAGE-1 ring slots
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s) issue_next(s);
+
+    int slot = 0;
+    const int h = lane >> 5;
+    const int l15 = lane & 15;
+    const int l31 = lane & 31;
+
+    for (int tile = t0; tile < t1; ++tile) {
+        for (int ks = 0; ks < KS; ++ks, ++f) {
+            // stage f has landed once at most (NSTAGE-2) younger stages are outstanding
+            if (total_stages - 1 - f >= NSTAGE - 2) wait_vmcnt<(NSTAGE - 2) * IPS>();
+            else wait_vmcnt<0>();
+            wg_barrier();
+            if (ks == 0 && tile > t0) {
+                // every wave has finished the previous tile's epilogue
+                if (__builtin_amdgcn_readfirstlane(*(volatile u32*)sFlag)) compact_pass(false);
+            }
+            // slot (slot-1) was consumed by every wave before the barrier above
+            issue_next((slot + NSTAGE - 1) % NSTAGE);
+
+            const char* sA = smem + slot * STAGE_BYTES;
+            const char* sB = sA + A_BYTES;
+#pragma unroll
+            for (int j = 0; j < BK / 8; ++j) {
+                const int coff = ((2 * j + h) ^ l15) << 4;
+                float4 af[MB], bf[QB];
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+                    af[m] = *reinterpret_cast<const float4*>(sA + ((wm * MB + m) * 32 + l31) * ROW_BYTES + coff);
+#pragma unroll
+                for (int q = 0; q < QB; ++q)
+                    bf[q] = *reinterpret_cast<const float4*>(sB + ((wq * QB + q) * 32 + l31) * ROW_BYTES + coff);
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int q = 0; q < QB; ++q) {
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, bf[q].x, acc[m][q], 0, 0, 0);
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, bf[q].y, acc[m][q], 0, 0, 0);
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, bf[q].z, acc[m][q], 0, 0, 0);
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf[q].w, acc[m][q], 0, 0, 0);
+                    }
+            }
+            slot = (slot + 1) % NSTAGE;
+        }
+
+        // ---- epilogue of one tile: threshold filter, append survivors ----
+        const long long row0 = (long long)tile * BM;
+#pragma unroll
+        for (int q = 0; q < QB; ++q) {
+            const int ql = (wq * QB + q) * 32 + l31;
+            const u32 thr = sThr[ql];
+            u64* qbuf = candBase + (size_t)ql * CAP;
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rt = (wm * MB + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const long long grow = row0 + rt;
+                    const u32 key = f2key(acc[m][q][r]);
+                    if (key > thr && grow < a.n) {
+                        const u32 pos = atomicAdd(&sCnt[ql], 1u);
+                        if (pos < (u32)CAP) qbuf[pos] = ((u64)key << 32) | (u64)(0xFFFFFFFFu - (u32)grow);
+                        if (pos + 1 > (u32)(CAP - BM)) *sFlag = 1;
+                    }
+                    acc[m][q][r] = 0.0f;
+                }
+            }
+        }
+    }
+
+    // ---- end of strip: leave at most k composites per query, publish counts ----
+    compact_pass(true);
+    for (int i = tid; i < BQ; i += NTHREADS) a.cnt[(size_t)strip * a.nq_pad + q0 + i] = sCnt[i];
+}
+
+// queries -> zero-padded [nq_pad][ld]
+__global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long long rows,
+                                long long rows_pad, int d, int ld) {
+    const long long total = rows_pad * ld;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / ld;
+        const int c = (int)(i - r * ld);
+        dst[i] = (r < rows && c < d) ? src[r * d + c] : 0.0f;
+    }
+}
+
+// ---- merge: bitonic sort (descending) of the composites of one query ----
+struct MergeArgs {
+    const u64* in;       // [S_in][nq_pad][cap_in]
+    const u32* in_cnt;   // [S_in][nq_pad]
+    u64* out;            // [S_out][nq_pad][k]       (intermediate levels)
+    u32* out_cnt;        // [S_out][nq_pad]
+    float* D;            // [nq][k]                   (final level)
+    long long* I;        // [nq][k]
+    long long id_base;
+    int cap_in;
+    int S_in;
+    int fan;             // strips merged by one workgroup
+    int nq_pad;
+    int k;
+    int npad;            // power of two >= fan * min(cap_in, k)
+    int final_level;
+};
+
+__device__ __forceinline__ void bitonic_desc_u64(u64* l, int n, int tid) {
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = tid; i < (n >> 1); i += NTHREADS) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const u64 x = l[lo], y = l[hi];
+                if ((x < y) == desc) { l[lo] = y; l[hi] = x; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(NTHREADS) void merge_kernel(MergeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* l = reinterpret_cast<u64*>(smem);
+    const int q = blockIdx.x;
+    const int g = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int s0 = g * a.fan;
+    const int s1 = min(a.S_in, s0 + a.fan);
+    int off = 0;
+    for (int s = s0; s < s1; ++s) {
+        int c = (int)a.in_cnt[(size_t)s * a.nq_pad + q];
+        c = min(c, a.k);
+        const u64* src = a.in + ((size_t)s * a.nq_pad + q) * a.cap_in;
+        for (int i = tid; i < c; i += NTHREADS) l[off + i] = src[i];
+        off += c;
+    }
+    for (int i = off + tid; i < a.npad; i += NTHREADS) l[i] = 0ull;
+    bitonic_desc_u64(l, a.npad, tid);
+    const int total = min(off, a.k);
+    if (a.final_level) {
+        for (int t = tid; t < a.k; t += NTHREADS) {
+            const u64 e = l[t];
+            const bool valid = t < total;
+            a.D[(size_t)q * a.k + t] = valid ? key2f((u32)(e >> 32)) : -FLT_MAX;
+            a.I[(size_t)q * a.k + t] = valid ? a.id_base + (long long)(0xFFFFFFFFu - (u32)e) : -1ll;
+        }
+    } else {
+        u64* dst = a.out + ((size_t)g * a.nq_pad + q) * a.k;
+        for (int t = tid; t < total; t += NTHREADS) dst[t] = l[t];
+        if (tid == 0) a.out_cnt[(size_t)g * a.nq_pad + q] = (u32)total;
+    }
+}
+
+// ---- merge of G sorted (D, I) lists per query: the sharded search's last step ----
+struct PairMergeArgs {
+    const float* Dc;       // [G][nq][k]
+    const long long* Ic;   // [G][nq][k]
+    float* D;              // [nq][k]
+    long long* I;
+    long long nq;
+    int G;
+    int k;
+    int npad;
+};
+
+__device__ __forceinline__ bool pair_before(u32 ka, long long ia, u32 kb, long long ib) {
+    return ka > kb || (ka == kb && ia < ib);
+}
+
+__global__ __launch_bounds__(NTHREADS) void pair_merge_kernel(PairMergeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    long long* lid = reinterpret_cast<long long*>(smem);
+    u32* lkey = reinterpret_cast<u32*>(smem + (size_t)a.npad * 8);
+    const long long q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n = a.G * a.k;
+    for (int i = tid; i < a.npad; i += NTHREADS) {
+        u32 key = 0;
+        long long id = 0x7FFFFFFFFFFFFFFFll;  // padding ranks last
+        if (i < n) {
+            const int g = i / a.k, t = i - g * a.k;
+            const size_t src = ((size_t)g * a.nq + q) * a.k + t;
+            const long long v = a.Ic[src];
+            if (v >= 0) { id = v; key = f2key(a.Dc[src]); }
+        }
+        lkey[i] = key;
+        lid[i] = id;
+    }
+    for (int size = 2; size <= a.npad; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = tid; i < (a.npad >> 1); i += NTHREADS) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const u32 kx = lkey[lo], ky = lkey[hi];
+                const long long ix = lid[lo], iy = lid[hi];
+                // descending run: the element that ranks first goes to `lo`
+                const bool swap = desc ? pair_before(ky, iy, kx, ix) : pair_before(kx, ix, ky, iy);
+                if (swap) { lkey[lo] = ky; lkey[hi] = kx; lid[lo] = iy; lid[hi] = ix; }
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < a.k; t += NTHREADS) {
+        const bool valid = lid[t] != 0x7FFFFFFFFFFFFFFFll;
+        a.D[(size_t)q * a.k + t] = valid ? key2f(lkey[t]) : -FLT_MAX;
+        a.I[(size_t)q * a.k + t] = valid ? lid[t] : -1ll;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+
+constexpr int MAX_SELECT = 8192;       // composites one merge workgroup sorts in LDS
+constexpr long long QCHUNK = 16384;    // queries per scan launch (bounds scratch)
+
+struct ScanCfg {
+    int bm, bq, cap;
+    size_t lds;
+    void (*launch)(const ScanArgs&, int grid, size_t lds, hipStream_t);
+};
+
+template <int WM, int WQ, int MB, int QB, int NSTAGE, int EPL>
+void launch_scan(const ScanArgs& a, int grid, size_t lds, hipStream_t st) {
+    auto kern = scan_kernel<WM, WQ, MB, QB, NSTAGE, EPL>;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, a);
+}
+
+template <int WM, int WQ, int MB, int QB, int NSTAGE, int EPL>
+ScanCfg make_cfg() {
+    constexpr int BM = WM * MB * 32, BQ = WQ * QB * 32;
+    ScanCfg c;
+    c.bm = BM;
+    c.bq = BQ;
+    c.cap = EPL * 64;
+    c.lds = (size_t)NSTAGE * (BM + BQ) * ROW_BYTES + (size_t)(2 * BQ + 4) * sizeof(u32);
+    c.launch = &launch_scan<WM, WQ, MB, QB, NSTAGE, EPL>;
+    return c;
+}
+
+// query-tile shapes: S (<=32 queries, HBM-bound), M (<=64), L (MFMA-bound)
+template <int EPL>
+ScanCfg pick_shape(long long nq) {
+    if (nq <= 32) return make_cfg<4, 1, 1, 1, 3, EPL>();
+    if (nq <= 64) return make_cfg<4, 1, 1, 2, 3, EPL>();
+    return make_cfg<2, 2, 2, 2, 2, EPL>();
+}
+
+int pick_cfg(long long nq, int k, ScanCfg* out) {
+    if (k <= 128) *out = pick_shape<6>(nq);
+    else if (k <= 512) *out = pick_shape<18>(nq);
+    else if (k <= 1024) *out = pick_shape<34>(nq);
+    else if (k <= 2048) *out = pick_shape<66>(nq);
+    else return set_err(OTTER_EINVAL, "search: k=%d exceeds OTTER_MAX_K=%d", k, OTTER_MAX_K);
+    return OTTER_OK;
+}
+
+int next_pow2(int x) {
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+}  // namespace
+
+struct otter_index {
+    int d = 0, ld = 0, dtype = OTTER_F32, device = 0, ncu = 256;
+    long long n = 0, cap_rows = 0, id_base = 0;
+    float* x = nullptr;
+    otter::DevBuf qpad, cand, cnt, lvl[2], lvlcnt[2], io_q, io_D, io_I;
+};
+
+namespace {
+
+int index_reserve_rows(otter_index* ix, long long need_rows, hipStream_t st) {
+    if (need_rows <= ix->cap_rows) return OTTER_OK;
+    long long want = ix->cap_rows == 0 ? need_rows : std::max(need_rows, ix->cap_rows + ix->cap_rows / 2);
+    float* nx = nullptr;
+    hipError_t e = hipMalloc((void**)&nx, (size_t)want * ix->ld * sizeof(float));
+    if (e != hipSuccess && want > need_rows) {
+        (void)hipGetLastError();
+        want = need_rows;
+        e = hipMalloc((void**)&nx, (size_t)want * ix->ld * sizeof(float));
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return set_err(OTTER_ENOMEM, "add: hipMalloc of %lld rows x %d floats failed: %s", want, ix->ld,
+                       hipGetErrorString(e));
+    }
+    if (ix->n > 0) {
+        OTTER_HIP_TRY(hipMemcpyAsync(nx, ix->x, (size_t)ix->n * ix->ld * sizeof(float), hipMemcpyDeviceToDevice, st));
+        OTTER_HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (ix->x) OTTER_HIP_TRY(hipFree(ix->x));
+    ix->x = nx;
+    ix->cap_rows = want;
+    return OTTER_OK;
+}
+
+// one scan + merge over queries [qd, qd + nq) (device pointers), results to device D/I
+int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st) {
+    ScanCfg cfg;
+    int rc = pick_cfg(nq, k, &cfg);
+    if (rc) return rc;
+    const long long nq_pad = round_up64(nq, cfg.bq);
+    const int qtiles = (int)(nq_pad / cfg.bq);
+    const int total_tiles = (int)((ix->n + cfg.bm - 1) / cfg.bm);
+    int strips = std::max(1, ix->ncu / qtiles);
+    strips = std::min(strips, total_tiles);
+
+    if ((rc = ix->qpad.reserve((size_t)nq_pad * ix->ld * sizeof(float)))) return rc;
+    if ((rc = ix->cand.reserve((size_t)strips * nq_pad * cfg.cap * sizeof(u64)))) return rc;
+    if ((rc = ix->cnt.reserve((size_t)strips * nq_pad * sizeof(u32)))) return rc;
+
+    {
+        const long long total = nq_pad * ix->ld;
+        const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(pad_rows_kernel, dim3(grid), dim3(256), 0, st, qd, (float*)ix->qpad.p, nq, nq_pad, ix->d,
+                           ix->ld);
+    }
+
+    ScanArgs sa;
+    sa.X = ix->x;
+    sa.Q = (const float*)ix->qpad.p;
+    sa.cand = (u64*)ix->cand.p;
+    sa.cnt = (u32*)ix->cnt.p;
+    sa.n = ix->n;
+    sa.ld = ix->ld;
+    sa.nq = (int)nq;
+    sa.nq_pad = (int)nq_pad;
+    sa.k = k;
+    sa.qtiles = qtiles;
+    sa.strips = strips;
+    sa.total_tiles = total_tiles;
+    cfg.launch(sa, qtiles * strips, cfg.lds, st);
+    OTTER_HIP_TRY(hipGetLastError());
+
+    // merge levels: S strips -> 1
+    const int fan = std::max(2, MAX_SELECT / k);
+    const u64* in = (const u64*)ix->cand.p;
+    const u32* in_cnt = (const u32*)ix->cnt.p;
+    int cap_in = cfg.cap;
+    int S_in = strips;
+    int pp = 0;
+    for (;;) {
+        const int S_out = (S_in + fan - 1) / fan;
+        const bool fin = S_out == 1;
+        MergeArgs ma;
+        ma.in = in;
+        ma.in_cnt = in_cnt;
+        ma.out = nullptr;
+        ma.out_cnt = nullptr;
+        ma.D = D;
+        ma.I = I;
+        ma.id_base = ix->id_base;
+        ma.cap_in = cap_in;
+        ma.S_in = S_in;
+        ma.fan = fan;
+        ma.nq_pad = (int)nq_pad;
+        ma.k = k;
+        ma.npad = next_pow2(std::max(2, std::min(S_in, fan) * k));
+        ma.npad = std::max(ma.npad, next_pow2(k));
+        ma.final_level = fin ? 1 : 0;
+        if (!fin) {
+            if ((rc = ix->lvl[pp].reserve((size_t)S_out * nq_pad * k * sizeof(u64)))) return rc;
+            if ((rc = ix->lvlcnt[pp].reserve((size_t)S_out * nq_pad * sizeof(u32)))) return rc;
+            ma.out = (u64*)ix->lvl[pp].p;
+            ma.out_cnt = (u32*)ix->lvlcnt[pp].p;
+        }
+        const size_t lds = (size_t)ma.npad * sizeof(u64);
+        static bool attr_set[64] = {};
+        if (ix->device < 64 && !attr_set[ix->device]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(merge_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SELECT * 2 * (int)sizeof(u64));
+            attr_set[ix->device] = true;
+        }
+        hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq, (unsigned)S_out), dim3(NTHREADS), lds, st, ma);
+        OTTER_HIP_TRY(hipGetLastError());
+        if (fin) break;
+        in = ma.out;
+        in_cnt = ma.out_cnt;
+        cap_in = k;
+        S_in = S_out;
+        pp ^= 1;
+    }
+    return OTTER_OK;
+}
+
+// n == 0: every result is padding
+__global__ void fill_empty_kernel(float* D, long long* I, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        D[i] = -FLT_MAX;
+        I[i] = -1;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int otter_index_create(int d, int dtype, int device, otter_index** out) {
+    if (!out) return set_err(OTTER_EINVAL, "index_create: out is NULL");
+    *out = nullptr;
+    if (d <= 0 || d > (1 << 20)) return set_err(OTTER_EINVAL, "index_create: bad dimension d=%d", d);
+    if (dtype != OTTER_F32)
+        return set_err(OTTER_ENOTIMPL, "index_create: only OTTER_F32 corpus storage is built (dtype=%d)", dtype);
+    int ndev = 0;
+    OTTER_HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+        return set_err(OTTER_EINVAL, "index_create: device %d out of range (%d visible)", device, ndev);
+    hipDeviceProp_t prop;
+    OTTER_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_err(OTTER_ESTATE, "index_create: device %d is %s; this library is built for gfx950 only", device,
+                       prop.gcnArchName);
+    otter_index* ix = new (std::nothrow) otter_index();
+    if (!ix) return set_err(OTTER_ENOMEM, "index_create: host allocation failed");
+    ix->d = d;
+    ix->ld = round_up(d, BK);
+    ix->dtype = dtype;
+    ix->device = device;
+    ix->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    *out = ix;
+    return OTTER_OK;
+}
+
+int otter_index_add(otter_index* ix, const void* x, int64_t n, int x_is_device, void* stream) {
+    if (!ix) return set_err(OTTER_EINVAL, "add: index is NULL");
+    if (n < 0) return set_err(OTTER_EINVAL, "add: n=%lld < 0", (long long)n);
+    if (n == 0) return OTTER_OK;
+    if (!x) return set_err(OTTER_EINVAL, "add: x is NULL");
+    if (ix->n + n > 0xFFFFFFF0ll)
+        return set_err(OTTER_EINVAL, "add: %lld rows exceed the 32-bit local id space of one index; shard the corpus",
+                       (long long)(ix->n + n));
+    DeviceGuard g(ix->device);
+    if (!g.ok) return set_err(OTTER_EHIP, "add: hipSetDevice(%d) failed", ix->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = index_reserve_rows(ix, ix->n + n, st);
+    if (rc) return rc;
+    float* dst = ix->x + (size_t)ix->n * ix->ld;
+    const hipMemcpyKind kind = x_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (ix->ld == ix->d) {
+        OTTER_HIP_TRY(hipMemcpyAsync(dst, x, (size_t)n * ix->d * sizeof(float), kind, st));
+    } else {
+        OTTER_HIP_TRY(hipMemsetAsync(dst, 0, (size_t)n * ix->ld * sizeof(float), st));
+        OTTER_HIP_TRY(hipMemcpy2DAsync(dst, (size_t)ix->ld * sizeof(float), x, (size_t)ix->d * sizeof(float),
+                                       (size_t)ix->d * sizeof(float), (size_t)n, kind, st));
+    }
+    if (!x_is_device) OTTER_HIP_TRY(hipStreamSynchronize(st));
+    ix->n += n;
+    return OTTER_OK;
+}
+
+int otter_index_search(otter_index* ix, const void* q, int64_t nq, int k, float* D, int64_t* I, int io_is_device,
+                       void* stream) {
+    if (!ix) return set_err(OTTER_EINVAL, "search: index is NULL");
+    if (nq < 0) return set_err(OTTER_EINVAL, "search: nq=%lld < 0", (long long)nq);
+    if (k < 1 || k > OTTER_MAX_K) return set_err(OTTER_EINVAL, "search: k=%d outside [1, %d]", k, OTTER_MAX_K);
+    if (nq == 0) return OTTER_OK;
+    if (!q || !D || !I) return set_err(OTTER_EINVAL, "search: q, D and I must be non-NULL");
+    DeviceGuard g(ix->device);
+    if (!g.ok) return set_err(OTTER_EHIP, "search: hipSetDevice(%d) failed", ix->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+
+    const float* qd = (const float*)q;
+    float* Dd = D;
+    long long* Id = (long long*)I;
+    if (!io_is_device) {
+        if ((rc = ix->io_q.reserve((size_t)nq * ix->d * sizeof(float)))) return rc;
+        if ((rc = ix->io_D.reserve((size_t)nq * k * sizeof(float)))) return rc;
+        if ((rc = ix->io_I.reserve((size_t)nq * k * sizeof(long long)))) return rc;
+        OTTER_HIP_TRY(hipMemcpyAsync(ix->io_q.p, q, (size_t)nq * ix->d * sizeof(float), hipMemcpyHostToDevice, st));
+        qd = (const float*)ix->io_q.p;
+        Dd = (float*)ix->io_D.p;
+        Id = (long long*)ix->io_I.p;
+    }
+
+    if (ix->n == 0) {
+        const long long total = (long long)nq * k;
+        hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)),
+                           dim3(256), 0, st, Dd, Id, total);
+        OTTER_HIP_TRY(hipGetLastError());
+    } else {
+        for (long long q0 = 0; q0 < nq; q0 += QCHUNK) {
+            const long long c = std::min<long long>(QCHUNK, nq - q0);
+            rc = search_chunk(ix, qd + (size_t)q0 * ix->d, c, k, Dd + (size_t)q0 * k, Id + (size_t)q0 * k, st);
+            if (rc) return rc;
+        }
+    }
+
+    if (!io_is_device) {
+        OTTER_HIP_TRY(hipMemcpyAsync(D, Dd, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
+        OTTER_HIP_TRY(hipMemcpyAsync(I, Id, (size_t)nq * k * sizeof(long long), hipMemcpyDeviceToHost, st));
+        OTTER_HIP_TRY(hipStreamSynchronize(st));
+    }
+    return OTTER_OK;
+}
+
+int64_t otter_index_ntotal(const otter_index* ix) { return ix ? ix->n : -1; }
+int otter_index_d(const otter_index* ix) { return ix ? ix->d : -1; }
+
+int otter_index_reset(otter_index* ix) {
+    if (!ix) return set_err(OTTER_EINVAL, "reset: index is NULL");
+    ix->n = 0;
+    return OTTER_OK;
+}
+
+int otter_index_set_id_base(otter_index* ix, int64_t id_base) {
+    if (!ix) return set_err(OTTER_EINVAL, "set_id_base: index is NULL");
+    if (id_base < 0) return set_err(OTTER_EINVAL, "set_id_base: id_base=%lld < 0", (long long)id_base);
+    ix->id_base = id_base;
+    return OTTER_OK;
+}
+
+void otter_index_destroy(otter_index* ix) {
+    if (!ix) return;
+    DeviceGuard g(ix->device);
+    if (ix->x) (void)hipFree(ix->x);
+    ix->qpad.release();
+    ix->cand.release();
+    ix->cnt.release();
+    for (int i = 0; i < 2; ++i) { ix->lvl[i].release(); ix->lvlcnt[i].release(); }
+    ix->io_q.release();
+    ix->io_D.release();
+    ix->io_I.release();
+    delete ix;
+}
+
+int otter_merge_topk(int device, const float* Dc, const int64_t* Ic, int G, int64_t nq, int k, float* D, int64_t* I,
+                     void* stream) {
+    if (G < 1 || k < 1 || nq < 0) return set_err(OTTER_EINVAL, "merge_topk: bad G=%d k=%d nq=%lld", G, k, (long long)nq);
+    if ((long long)G * k > MAX_SELECT)
+        return set_err(OTTER_EINVAL, "merge_topk: G*k=%lld exceeds %d; merge hierarchically", (long long)G * k,
+                       MAX_SELECT);
+    if (nq == 0) return OTTER_OK;
+    if (!Dc || !Ic || !D || !I) return set_err(OTTER_EINVAL, "merge_topk: NULL buffer");
+    DeviceGuard g(device);
+    if (!g.ok) return set_err(OTTER_EHIP, "merge_topk: hipSetDevice(%d) failed", device);
+    PairMergeArgs a;
+    a.Dc = Dc;
+    a.Ic = (const long long*)Ic;
+    a.D = D;
+    a.I = (long long*)I;
+    a.nq = nq;
+    a.G = G;
+    a.k = k;
+    a.npad = next_pow2(std::max(2, G * k));
+    const size_t lds = (size_t)a.npad * 12;
+    static bool attr_set[64] = {};
+    if (device < 64 && !attr_set[device]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pair_merge_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SELECT * 12);
+        attr_set[device] = true;
+    }
+    hipLaunchKernelGGL(pair_merge_kernel, dim3((unsigned)nq), dim3(NTHREADS), lds, (hipStream_t)stream, a);
+    OTTER_HIP_TRY(hipGetLastError());
+    return OTTER_OK;
+}
+
+}  // extern "C"

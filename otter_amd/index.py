@@ -1,0 +1,160 @@
+"""IndexFlatIP — the faiss surface the reference's eval path uses, on one MI355X.
+
+Mirrors `index = faiss.IndexFlatIP(d); index.add(xb); D, I = index.search(q, k)`
+(reference scripts/eval_ottqa_retrieval.py:108-109,129): same names, same argument
+meaning, same result layout (D float32 [nq, k] descending, I int64 [nq, k], -1 padding).
+numpy in -> numpy out (host copies); torch device tensors in -> torch device tensors
+out (zero copy, work only enqueued on the current stream).
+
+All compute happens in libotter_hip.so (otter_amd/csrc/index.hip); there is no CPU path.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+try:  # torch is plumbing only (device memory + streams); numpy-only callers do not need it
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _is_torch(x):
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _stream_ptr(device_index):
+    if torch is None or not torch.cuda.is_available():
+        return None
+    return ctypes.c_void_p(torch.cuda.current_stream(device_index).cuda_stream)
+
+
+class IndexFlatIP:
+    """Exact inner-product index resident in the HBM of one GPU.
+
+    Parameters
+    ----------
+    d : int            vector dimension (768, or 768*3 for the reference's three-cat embeddings)
+    device : int       HIP device ordinal
+    id_base : int      added to every reported id (row-sharded use: the shard's first global row)
+    """
+
+    def __init__(self, d, device=0, id_base=0):
+        self._lib = _lib.load()
+        self.d = int(d)
+        self.device = int(device)
+        self._h = ctypes.c_void_p()
+        _lib.check(self._lib.otter_index_create(self.d, _lib.OTTER_F32, self.device, ctypes.byref(self._h)),
+                   "otter_index_create")
+        self.id_base = 0
+        if id_base:
+            self.set_id_base(id_base)
+
+    # -- faiss attributes
+    @property
+    def ntotal(self):
+        return int(self._lib.otter_index_ntotal(self._h))
+
+    @property
+    def is_trained(self):
+        return True
+
+    def set_id_base(self, id_base):
+        _lib.check(self._lib.otter_index_set_id_base(self._h, int(id_base)), "otter_index_set_id_base")
+        self.id_base = int(id_base)
+
+    def add(self, x):
+        """index.add(xb): x float32 [n, d], numpy (host) or torch tensor on this index's device."""
+        if _is_torch(x):
+            if x.dim() != 2 or x.shape[1] != self.d:
+                raise ValueError("add: expected [n, %d], got %r" % (self.d, tuple(x.shape)))
+            if x.is_cuda:
+                if x.device.index != self.device:
+                    raise ValueError("add: tensor on %s, index on device %d" % (x.device, self.device))
+                x = x.to(torch.float32).contiguous()
+                _lib.check(self._lib.otter_index_add(self._h, ctypes.c_void_p(x.data_ptr()), x.shape[0], 1,
+                                                     _stream_ptr(self.device)), "otter_index_add")
+                # the copy into the index's private HBM is only enqueued: keep x alive until it ran
+                torch.cuda.current_stream(self.device).synchronize()
+                return
+            x = x.detach().cpu().numpy()
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise ValueError("add: expected [n, %d] float32, got %r" % (self.d, x.shape))
+        _lib.check(self._lib.otter_index_add(self._h, ctypes.c_void_p(x.ctypes.data), x.shape[0], 0,
+                                             _stream_ptr(self.device)), "otter_index_add")
+
+    def search(self, q, k):
+        """D, I = index.search(q, k)."""
+        k = int(k)
+        if k < 1 or k > _lib.OTTER_MAX_K:
+            raise ValueError("search: k=%d outside [1, %d]" % (k, _lib.OTTER_MAX_K))
+        if _is_torch(q) and q.is_cuda:
+            if q.dim() != 2 or q.shape[1] != self.d:
+                raise ValueError("search: expected [nq, %d], got %r" % (self.d, tuple(q.shape)))
+            if q.device.index != self.device:
+                raise ValueError("search: tensor on %s, index on device %d" % (q.device, self.device))
+            q = q.to(torch.float32).contiguous()
+            nq = q.shape[0]
+            D = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+            _lib.check(self._lib.otter_index_search(self._h, ctypes.c_void_p(q.data_ptr()), nq, k,
+                                                    ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()), 1,
+                                                    _stream_ptr(self.device)), "otter_index_search")
+            return D, I
+        if _is_torch(q):
+            q = q.detach().numpy()
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self.d:
+            raise ValueError("search: expected [nq, %d] float32, got %r" % (self.d, q.shape))
+        nq = q.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        _lib.check(self._lib.otter_index_search(self._h, ctypes.c_void_p(q.ctypes.data), nq, k,
+                                                ctypes.c_void_p(D.ctypes.data), ctypes.c_void_p(I.ctypes.data), 0,
+                                                _stream_ptr(self.device)), "otter_index_search")
+        return D, I
+
+    def reset(self):
+        _lib.check(self._lib.otter_index_reset(self._h), "otter_index_reset")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.otter_index_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def merge_topk(Dc, Ic, device=None):
+    """Merge G per-shard results: Dc float32 [G, nq, k], Ic int64 [G, nq, k] (torch, on one
+    GPU) -> (D [nq, k], I [nq, k]).  Hierarchical when G*k exceeds one workgroup's select."""
+    if not (_is_torch(Dc) and Dc.is_cuda and _is_torch(Ic) and Ic.is_cuda):
+        raise ValueError("merge_topk: expects CUDA/HIP torch tensors")
+    lib = _lib.load()
+    G, nq, k = Dc.shape
+    dev = Dc.device.index if device is None else int(device)
+    Dc = Dc.to(torch.float32).contiguous()
+    Ic = Ic.to(torch.int64).contiguous()
+    while True:
+        g_step = max(2, _lib.MERGE_MAX // k)
+        if g_step * k > _lib.MERGE_MAX:
+            raise ValueError("merge_topk: k=%d too large to merge" % k)
+        groups = [(g0, min(G, g0 + g_step)) for g0 in range(0, G, g_step)]
+        Do = torch.empty((len(groups), nq, k), dtype=torch.float32, device=Dc.device)
+        Io = torch.empty((len(groups), nq, k), dtype=torch.int64, device=Dc.device)
+        for gi, (g0, g1) in enumerate(groups):
+            dsub = Dc[g0:g1].contiguous()
+            isub = Ic[g0:g1].contiguous()
+            _lib.check(lib.otter_merge_topk(dev, ctypes.c_void_p(dsub.data_ptr()), ctypes.c_void_p(isub.data_ptr()),
+                                            g1 - g0, nq, k, ctypes.c_void_p(Do[gi].data_ptr()),
+                                            ctypes.c_void_p(Io[gi].data_ptr()), _stream_ptr(dev)),
+                       "otter_merge_topk")
+        if len(groups) == 1:
+            return Do[0], Io[0]
+        Dc, Ic, G = Do, Io, len(groups)

@@ -1,0 +1,150 @@
+"""GPU parity of the HIP index (through the C ABI) against the CPU oracle.
+
+Oracle: oracle/flat_ip.c mode 1 reproduces the kernel's fp32 fma order, so D and I
+must match BIT FOR BIT; independently, oracle.flat_ip.check_topk applies the
+order-free rule of SURVEY.md §8c (float64 arbiter, tolerance 1e-5*|q|*max|x|).
+Parity vs faiss itself is unpinned (faiss absent; see oracle/flat_ip.c header).
+"""
+import numpy as np
+import pytest
+
+from oracle import flat_ip
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(n, d, nq, seed):
+    rng = np.random.RandomState(seed)
+    return rng.randn(n, d).astype(np.float32), rng.randn(nq, d).astype(np.float32)
+
+
+def _search(xb, q, k, chunks=1):
+    from otter_amd.index import IndexFlatIP
+    ix = IndexFlatIP(xb.shape[1])
+    for part in np.array_split(xb, chunks):
+        ix.add(part)
+    assert ix.ntotal == xb.shape[0]
+    D, I = ix.search(q, k)
+    ix.close()
+    return D, I
+
+
+CASES = [
+    # n, d, nq, k
+    (100, 768, 1, 1),
+    (100, 768, 7, 100),
+    (100, 768, 7, 1000),     # k > n: -1 padding
+    (4096, 768, 1, 100),
+    (4096, 768, 64, 100),
+    (4096, 2304, 7, 100),
+    (5000, 100, 33, 10),     # d not a multiple of 64, 64-query tile
+    (65536, 768, 7, 100),
+    (65536, 768, 200, 100),  # 128-query tile, ragged query count
+    (65536, 768, 64, 1000),
+    (20000, 768, 130, 2048),
+    (300, 768, 5, 129),
+    (70000, 64, 32, 500),
+]
+
+
+@pytest.mark.parametrize("n,d,nq,k", CASES)
+def test_search_matches_oracle(n, d, nq, k):
+    xb, q = _mk(n, d, nq, seed=n + d + nq + k)
+    D, I = _search(xb, q, k)
+    Dr, Ir = flat_ip.search_c(xb, q, k, mode=flat_ip.MODE_GPU_ORDER)
+    assert D.dtype == np.float32 and I.dtype == np.int64
+    np.testing.assert_array_equal(I, Ir)
+    np.testing.assert_array_equal(D.view(np.uint32), Dr.view(np.uint32))
+    flat_ip.check_topk(xb, q, D, I, k, rtol=1e-5)
+
+
+def test_incremental_add_and_reset():
+    from otter_amd.index import IndexFlatIP
+    xb, q = _mk(3000, 768, 9, seed=5)
+    ix = IndexFlatIP(768)
+    ix.add(xb[:1000]); ix.add(xb[1000:1001]); ix.add(xb[1001:])
+    assert ix.ntotal == 3000 and ix.d == 768
+    D, I = ix.search(q, 50)
+    Dr, Ir = flat_ip.search_c(xb, q, 50)
+    np.testing.assert_array_equal(I, Ir)
+    ix.reset()
+    assert ix.ntotal == 0
+    D, I = ix.search(q, 5)
+    assert (I == -1).all() and (D == flat_ip.NEG).all()
+    ix.add(xb[:10])
+    D, I = ix.search(q, 5)
+    Dr, Ir = flat_ip.search_c(xb[:10], q, 5)
+    np.testing.assert_array_equal(I, Ir)
+
+
+def test_ties_duplicate_rows_and_all_equal():
+    rng = np.random.RandomState(11)
+    base = rng.randn(500, 768).astype(np.float32)
+    xb = np.concatenate([base, base, base[:100]], 0)      # every row 2-3 times: exact score ties
+    q = rng.randn(6, 768).astype(np.float32)
+    D, I = _search(xb, q, 100)
+    Dr, Ir = flat_ip.search_c(xb, q, 100)
+    np.testing.assert_array_equal(I, Ir)                  # (score desc, id asc)
+    np.testing.assert_array_equal(D, Dr)
+    xb = np.ones((1000, 768), np.float32)                 # all scores equal: ids 0..k-1
+    q = np.ones((3, 768), np.float32)
+    D, I = _search(xb, q, 100)
+    np.testing.assert_array_equal(I, np.tile(np.arange(100), (3, 1)))
+    assert (D == 768.0).all()
+    xb = np.zeros((700, 768), np.float32)
+    xb[::2] *= -1.0                                       # -0.0 rows tie with +0.0 rows
+    D, I = _search(xb, q, 10)
+    np.testing.assert_array_equal(I, np.tile(np.arange(10), (3, 1)))
+
+
+def test_negative_and_infinite_scores():
+    xb, q = _mk(2000, 768, 4, seed=3)
+    xb[5] = -np.inf
+    xb[7] = np.inf
+    xb *= 1.0
+    q = np.abs(q)
+    D, I = _search(xb, q, 2000)
+    assert (I[:, 0] == 7).all() and (I[:, -1] == 5).all()
+    assert np.isposinf(D[:, 0]).all() and np.isneginf(D[:, -1]).all()
+
+
+def test_torch_device_io_and_id_base():
+    import torch
+    from otter_amd.index import IndexFlatIP
+    xb, q = _mk(10000, 768, 40, seed=8)
+    ix = IndexFlatIP(768, device=0, id_base=1 << 33)
+    ix.add(torch.from_numpy(xb).cuda())
+    D, I = ix.search(torch.from_numpy(q).cuda(), 100)
+    assert D.is_cuda and I.is_cuda and I.dtype == torch.int64
+    Dr, Ir = flat_ip.search_c(xb, q, 100, id_base=1 << 33)
+    np.testing.assert_array_equal(I.cpu().numpy(), Ir)
+    np.testing.assert_array_equal(D.cpu().numpy(), Dr)
+
+
+def test_merge_topk_matches_oracle():
+    import torch
+    from otter_amd.index import merge_topk
+    rng = np.random.RandomState(2)
+    G, nq, k = 8, 50, 100
+    Dc = np.sort(rng.randn(G, nq, k).astype(np.float32), axis=2)[:, :, ::-1].copy()
+    Ic = rng.randint(0, 1 << 40, size=(G, nq, k)).astype(np.int64)
+    Dc[3, :, 60:] = flat_ip.NEG
+    Ic[3, :, 60:] = -1                                    # a short shard
+    Dc[5, 0, :] = Dc[4, 0, :]                             # cross-shard score ties
+    Dr, Ir = flat_ip.merge_c(Dc, Ic)
+    D, I = merge_topk(torch.from_numpy(Dc).cuda(), torch.from_numpy(Ic).cuda())
+    np.testing.assert_array_equal(I.cpu().numpy(), Ir)
+    np.testing.assert_array_equal(D.cpu().numpy(), Dr)
+
+
+def test_errors_are_loud():
+    from otter_amd.index import IndexFlatIP
+    ix = IndexFlatIP(768)
+    with pytest.raises(ValueError):
+        ix.add(np.zeros((3, 5), np.float32))
+    with pytest.raises(ValueError):
+        ix.search(np.zeros((3, 768), np.float32), 0)
+    with pytest.raises(ValueError):
+        ix.search(np.zeros((3, 768), np.float32), 4096)
+    with pytest.raises(ValueError):
+        IndexFlatIP(0)
