@@ -92,6 +92,14 @@ int otter_index_set_id_base(otter_index* ix, int64_t id_base);
 
 void otter_index_destroy(otter_index* ix);
 
+/* Measurement hook (no counterpart in the reference; used by bench.py for the
+ * roofline figure).  While enabled, search() brackets its scan kernel with HIP
+ * events on the caller's stream.  otter_index_timing() waits for the recorded
+ * events and returns the summed scan-kernel time and the number of launches
+ * since the previous call (at most 4096 launches are kept between calls). */
+int otter_index_set_timing(otter_index* ix, int enable);
+int otter_index_timing(otter_index* ix, double* scan_ms, int64_t* scan_launches);
+
 /* Final merge of the row-sharded search: G sorted candidate lists per query
  * (Dc float32 [G, nq, k], Ic int64 [G, nq, k], device pointers, as returned
  * by G per-shard search() calls and exchanged with an all-gather) are merged

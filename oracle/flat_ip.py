@@ -145,6 +145,45 @@ class IndexFlatIP:
         return D, I
 
 
+def search_batched(xb, q, k, block=16384):
+    """The batched form faiss takes for large nq: sgemm over corpus blocks (numpy -> BLAS,
+    multi-threaded) + per-row k-select (argpartition), exact under (score desc, id asc).
+    Used as the timed CPU baseline of bench.py ("port"); same results as IndexFlatIP.search."""
+    xb = np.ascontiguousarray(xb, dtype=np.float32)
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    nq, n = q.shape[0], xb.shape[0]
+    D = np.full((nq, k), NEG, dtype=np.float32)
+    I = np.full((nq, k), -1, dtype=np.int64)
+    if n == 0 or nq == 0:
+        return D, I
+    best_s = np.empty((nq, 0), dtype=np.float32)
+    best_i = np.empty((nq, 0), dtype=np.int64)
+    rows = np.arange(nq)[:, None]
+    for lo in range(0, n, block):
+        hi = min(n, lo + block)
+        s = q @ xb[lo:hi].T
+        nb = hi - lo
+        kk = min(k, nb)
+        if kk < nb:
+            sel = np.argpartition(-s, kk - 1, axis=1)[:, :kk]
+            thr = s[rows, sel].min(axis=1)
+            # ties at the cut: argpartition keeps an arbitrary subset of the rows equal to thr
+            tied = (s >= thr[:, None]).sum(axis=1) > kk
+            for r in np.nonzero(tied)[0]:
+                sel[r] = np.lexsort((np.arange(nb), -s[r].astype(np.float64)))[:kk]
+        else:
+            sel = np.broadcast_to(np.arange(nb), (nq, nb))
+        cs = np.concatenate([best_s, s[rows, sel]], axis=1)
+        ci = np.concatenate([best_i, sel.astype(np.int64) + lo], axis=1)
+        order = np.lexsort((ci, -cs.astype(np.float64)), axis=1)[:, :min(k, cs.shape[1])]
+        best_s = np.take_along_axis(cs, order, axis=1)
+        best_i = np.take_along_axis(ci, order, axis=1)
+    kk = best_s.shape[1]
+    D[:, :kk] = best_s
+    I[:, :kk] = best_i
+    return D, I
+
+
 def scores_f64(xb, q, ids):
     """float64 scores of the given (query, id) pairs; ids [nq, k] with -1 padding."""
     xb = np.asarray(xb, dtype=np.float64)

@@ -47,6 +47,8 @@ SIGNATURES = {
     "otter_index_reset": (c_int, [c_vp]),
     "otter_index_set_id_base": (c_int, [c_vp, c_i64]),
     "otter_index_destroy": (None, [c_vp]),
+    "otter_index_set_timing": (c_int, [c_vp, c_int]),
+    "otter_index_timing": (c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
     "otter_merge_topk": (c_int, [c_int, c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp]),
     "otter_encoder_create": (c_int, [ctypes.POINTER(EncoderCfg), c_int, ctypes.POINTER(c_vp)]),
     "otter_encoder_set_weight": (c_int, [c_vp, ctypes.c_char_p, c_vp, ctypes.POINTER(c_i64), c_int]),

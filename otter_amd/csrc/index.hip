@@ -16,9 +16,12 @@
 //            (larger composite == ranks earlier: score desc, id asc; composites are unique)
 //   cnt      [S][nq_pad] u32 number of valid composites
 #include <float.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <new>
+#include <utility>
+#include <vector>
 
 #include "otter_common.h"
 
@@ -62,6 +65,16 @@ __device__ __forceinline__ void dma16(const void* gsrc, u32 lds_dst) {
         "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+// Same with a wave-uniform 64-bit base (SGPR pair) and a per-lane 32-bit byte offset:
+// the per-lane part is computed once per kernel, the base with scalar ALU per stage.
+__device__ __forceinline__ void dma16s(const void* sbase, u32 voff, u32 lds_dst) {
+    u32 keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
         : "memory");
 }
 // workgroup barrier that does NOT drain the vector-memory queue (LDS-DMA stays in flight)
@@ -118,16 +131,19 @@ __device__ __forceinline__ u64 wave_compact(u64* base, int n, int k, int lane) {
 
 // WM x WQ waves; each wave owns (MB*32) corpus rows x (QB*32) queries of the tile.
 template <int WM, int WQ, int MB, int QB, int NSTAGE, int EPL>
-__global__ __launch_bounds__(NTHREADS, 1) void scan_kernel(ScanArgs a) {
-    static_assert(WM * WQ == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(WM * WQ * 64, WM * WQ / 4) void scan_kernel(ScanArgs a) {
+    constexpr int NW = WM * WQ;          // waves per workgroup (4: one per SIMD, 8: two)
+    constexpr int NT = NW * 64;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     constexpr int BM = WM * MB * 32;
     constexpr int BQ = WQ * QB * 32;
     constexpr int CAP = EPL * 64;
     constexpr int A_BYTES = BM * ROW_BYTES;
     constexpr int B_BYTES = BQ * ROW_BYTES;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int A_INSTR = BM / 16;  // LDS-DMA instructions per wave per stage (1 KiB = 4 rows each)
-    constexpr int B_INSTR = BQ / 16;
+    constexpr int A_INSTR = BM / 4 / NW;  // LDS-DMA instructions per wave per stage (1 KiB = 4 rows each)
+    constexpr int B_INSTR = BQ / 4 / NW;
+    static_assert(A_INSTR * 4 * NW == BM && B_INSTR * 4 * NW == BQ, "tile rows must split over the waves");
     constexpr int IPS = A_INSTR + B_INSTR;
     static_assert(CAP - BM >= 128, "candidate buffer too small");
 
@@ -142,14 +158,24 @@ __global__ __launch_bounds__(NTHREADS, 1) void scan_kernel(ScanArgs a) {
     const int wm = wave / WQ;
     const int wq = wave % WQ;
 
-    const int qt = blockIdx.x % a.qtiles;
-    const int strip = blockIdx.x / a.qtiles;
+    // XCD-aware placement: workgroups b, b+8, b+16, ... share an XCD (and its 4 MiB L2).
+    // Give each XCD a contiguous range of the (query tile, strip) list with the strip
+    // varying fastest, so that one XCD works on few query tiles (their 393 KB stay in
+    // its L2) while the corpus rows stream through.  Pure speed: any placement is correct.
+    int wg;
+    {
+        const int nwg = gridDim.x, per = nwg >> 3, rem = nwg & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        wg = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
+    }
+    const int qt = wg / a.strips;
+    const int strip = wg - qt * a.strips;
     const int q0 = qt * BQ;
     const int t0 = (int)(((long long)strip * a.total_tiles) / a.strips);
     const int t1 = (int)(((long long)(strip + 1) * a.total_tiles) / a.strips);
     const int KS = a.ld / BK;
 
-    for (int i = tid; i < BQ; i += NTHREADS) {
+    for (int i = tid; i < BQ; i += NT) {
         sCnt[i] = 0;
         sThr[i] = (q0 + i < a.nq) ? 0u : 0xFFFFFFFFu;  // padded queries never accept
     }
@@ -157,39 +183,43 @@ __global__ __launch_bounds__(NTHREADS, 1) void scan_kernel(ScanArgs a) {
 
     u64* candBase = a.cand + ((size_t)strip * a.nq_pad + q0) * CAP;
 
-    // ---- LDS-DMA producer: one k-stage of one tile into ring slot `slot` ----
+    // ---- LDS-DMA producer: one k-stage of one tile into a ring slot ----
     // LDS image of a stage: [row][16 chunks of 16 B]; chunk p of row r holds the
     // global chunk p ^ (r & 15) (swizzle on the SOURCE address; the DMA writes linearly).
+    // A stage is IPS wave-instructions of 1 KiB (4 rows) per wave.  Per-lane byte offsets
+    // are fixed for the whole kernel; the corpus allocation is padded to whole tiles, so
+    // no row clamp is needed (rows >= n are masked in the epilogue).
     const int dma_r = lane >> 4;   // row within the 4-row group of one instruction
     const int dma_p = lane & 15;   // LDS chunk position
     const u32 lds0 = (u32)(uintptr_t)(AS3 char*)smem;
-    auto issue_stage = [&](int tile, int ks, int slot) {
-        const u32 sA = lds0 + slot * STAGE_BYTES;
-        const u32 sB = sA + A_BYTES;
-        const long long row0 = (long long)tile * BM;
+    u32 voff[IPS];
 #pragma unroll
-        for (int ii = 0; ii < A_INSTR; ++ii) {
-            const int i = ii * 4 + wave;
-            const int r = 4 * i + dma_r;
-            long long grow = row0 + r;
-            grow = grow < a.n ? grow : a.n - 1;
-            const float* src = a.X + (size_t)grow * a.ld + ks * BK + ((dma_p ^ (r & 15)) << 2);
-            dma16(src, sA + i * 1024);
-        }
-#pragma unroll
-        for (int ii = 0; ii < B_INSTR; ++ii) {
-            const int i = ii * 4 + wave;
-            const int r = 4 * i + dma_r;
-            const float* src = a.Q + (size_t)(q0 + r) * a.ld + ks * BK + ((dma_p ^ (r & 15)) << 2);
-            dma16(src, sB + i * 1024);
+    for (int t = 0; t < IPS; ++t) {
+        const int i = (t < A_INSTR ? t : t - A_INSTR) * NW + wave;
+        const int r = 4 * i + dma_r;
+        voff[t] = ((u32)r * (u32)a.ld + (u32)((dma_p ^ (r & 15)) << 2)) * 4u;
+    }
+    const float* gQ = a.Q + (size_t)q0 * a.ld;
+
+    // the stage being produced: scalar bases + ring slot; pieces are issued one by one
+    int it_tile = t0, it_ks = 0;
+    bool pr_have = false;
+    const float* pr_gA = a.X;
+    const float* pr_gB = gQ;
+    u32 pr_lds = lds0;
+    auto produce_begin = [&](int slot) {
+        pr_have = it_tile < t1;
+        if (pr_have) {
+            pr_gA = a.X + ((size_t)it_tile * BM * a.ld + (size_t)it_ks * BK);
+            pr_gB = gQ + (size_t)it_ks * BK;
+            pr_lds = lds0 + slot * STAGE_BYTES;
+            if (++it_ks == KS) { it_ks = 0; ++it_tile; }
         }
     };
-
-    int it_tile = t0, it_ks = 0;
-    auto issue_next = [&](int slot) {
-        if (it_tile < t1) {
-            issue_stage(it_tile, it_ks, slot);
-            if (++it_ks == KS) { it_ks = 0; ++it_tile; }
+    auto produce_piece = [&](int t) {   // t in [0, IPS), compile-time after unrolling
+        if (pr_have) {
+            if (t < A_INSTR) dma16s(pr_gA, voff[t], pr_lds + (t * NW + wave) * 1024);
+            else dma16s(pr_gB, voff[t], pr_lds + A_BYTES + ((t - A_INSTR) * NW + wave) * 1024);
         }
     };
 
@@ -205,7 +235,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void scan_kernel(ScanArgs a) {
     auto compact_pass = [&](bool final_pass) {
         wait_vmcnt<0>();  // own candidate stores have reached L2
         wg_barrier();
-        for (int q = wave; q < BQ; q += 4) {
+        for (int q = wave; q < BQ; q += NW) {
             const int n = (int)sCnt[q];
             const bool need = final_pass ? (n > a.k) : (n > CAP - BM);
             if (need) {
@@ -226,7 +256,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void scan_kernel(ScanArgs a) {
 
     // prologue: fill NSTAGE-1 ring slots
 #pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s) issue_next(s);
+    for (int s = 0; s < NSTAGE - 1; ++s) {
+        produce_begin(s);
+#pragma unroll
+        for (int t = 0; t < IPS; ++t) produce_piece(t);
+    }
 
     int slot = 0;
     const int h = lane >> 5;
@@ -241,31 +275,43 @@ __global__ __launch_bounds__(NTHREADS, 1) void scan_kernel(ScanArgs a) {
             wg_barrier();
             if (ks == 0 && tile > t0) {
                 // every wave has finished the previous tile's epilogue
-                if (__builtin_amdgcn_readfirstlane(*(volatile u32*)sFlag)) compact_pass(false);
+                if (__builtin_amdgcn_readfirstlane(*sFlag)) compact_pass(false);  // LDS read, reloaded after the barrier
             }
-            // slot (slot-1) was consumed by every wave before the barrier above
-            issue_next((slot + NSTAGE - 1) % NSTAGE);
-
             const char* sA = smem + slot * STAGE_BYTES;
             const char* sB = sA + A_BYTES;
-#pragma unroll
-            for (int j = 0; j < BK / 8; ++j) {
+            // fragments of k-group j: 16 B per lane = 4 MFMA k-steps (k = 8j + 4h + t)
+            float4 af[2][MB], bf[2][QB];
+            auto load_frags = [&](int j, int buf) {
                 const int coff = ((2 * j + h) ^ l15) << 4;
-                float4 af[MB], bf[QB];
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
-                    af[m] = *reinterpret_cast<const float4*>(sA + ((wm * MB + m) * 32 + l31) * ROW_BYTES + coff);
+                    af[buf][m] =
+                        *reinterpret_cast<const float4*>(sA + ((wm * MB + m) * 32 + l31) * ROW_BYTES + coff);
 #pragma unroll
                 for (int q = 0; q < QB; ++q)
-                    bf[q] = *reinterpret_cast<const float4*>(sB + ((wq * QB + q) * 32 + l31) * ROW_BYTES + coff);
+                    bf[buf][q] =
+                        *reinterpret_cast<const float4*>(sB + ((wq * QB + q) * 32 + l31) * ROW_BYTES + coff);
+            };
+            load_frags(0, 0);
+            // slot (slot-1) was consumed by every wave before the barrier above: refill it
+            // with stage f+NSTAGE-1, a few pieces per k-group so the issue hides under MFMAs
+            produce_begin((slot + NSTAGE - 1) % NSTAGE);
+#pragma unroll
+            for (int j = 0; j < BK / 8; ++j) {
+                const int cb = j & 1;
+                if (j + 1 < BK / 8) load_frags(j + 1, cb ^ 1);  // register double buffer
+#pragma unroll
+                for (int t = j; t < IPS; t += BK / 8) produce_piece(t);
+                // keep the reads of group j+1 ahead of group j's MFMAs (hipcc sinks them otherwise)
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
 #pragma unroll
                     for (int q = 0; q < QB; ++q) {
-                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, bf[q].x, acc[m][q], 0, 0, 0);
-                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, bf[q].y, acc[m][q], 0, 0, 0);
-                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, bf[q].z, acc[m][q], 0, 0, 0);
-                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf[q].w, acc[m][q], 0, 0, 0);
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][m].x, bf[cb][q].x, acc[m][q], 0, 0, 0);
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][m].y, bf[cb][q].y, acc[m][q], 0, 0, 0);
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][m].z, bf[cb][q].z, acc[m][q], 0, 0, 0);
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][m].w, bf[cb][q].w, acc[m][q], 0, 0, 0);
                     }
             }
             slot = (slot + 1) % NSTAGE;
@@ -298,7 +344,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void scan_kernel(ScanArgs a) {
 
     // ---- end of strip: leave at most k composites per query, publish counts ----
     compact_pass(true);
-    for (int i = tid; i < BQ; i += NTHREADS) a.cnt[(size_t)strip * a.nq_pad + q0 + i] = sCnt[i];
+    for (int i = tid; i < BQ; i += NT) a.cnt[(size_t)strip * a.nq_pad + q0 + i] = sCnt[i];
 }
 
 // queries -> zero-padded [nq_pad][ld]
@@ -460,7 +506,7 @@ void launch_scan(const ScanArgs& a, int grid, size_t lds, hipStream_t st) {
                                   (int)lds);
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WQ * 64), lds, st, a);
 }
 
 template <int WM, int WQ, int MB, int QB, int NSTAGE, int EPL>
@@ -480,7 +526,9 @@ template <int EPL>
 ScanCfg pick_shape(long long nq) {
     if (nq <= 32) return make_cfg<4, 1, 1, 1, 3, EPL>();
     if (nq <= 64) return make_cfg<4, 1, 1, 2, 3, EPL>();
-    return make_cfg<2, 2, 2, 2, 2, EPL>();
+    static const bool w4 = getenv("OTTER_SCAN_W4") != nullptr;   // A/B switch for tuning runs
+    if (w4) return make_cfg<2, 2, 2, 2, 2, EPL>();
+    return make_cfg<2, 4, 2, 1, 2, EPL>();
 }
 
 int pick_cfg(long long nq, int k, ScanCfg* out) {
@@ -505,13 +553,19 @@ struct otter_index {
     long long n = 0, cap_rows = 0, id_base = 0;
     float* x = nullptr;
     otter::DevBuf qpad, cand, cnt, lvl[2], lvlcnt[2], io_q, io_D, io_I;
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
 };
 
 namespace {
 
 int index_reserve_rows(otter_index* ix, long long need_rows, hipStream_t st) {
     if (need_rows <= ix->cap_rows) return OTTER_OK;
+    // capacity is kept a multiple of the scan tile (128 rows): the kernel reads whole tiles
+    // and masks rows >= n, so the tail of the last tile must be addressable
+    need_rows = round_up64(need_rows, 128);
     long long want = ix->cap_rows == 0 ? need_rows : std::max(need_rows, ix->cap_rows + ix->cap_rows / 2);
+    want = round_up64(want, 128);
     float* nx = nullptr;
     hipError_t e = hipMalloc((void**)&nx, (size_t)want * ix->ld * sizeof(float));
     if (e != hipSuccess && want > need_rows) {
@@ -569,8 +623,24 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
     sa.qtiles = qtiles;
     sa.strips = strips;
     sa.total_tiles = total_tiles;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    const bool timed = ix->timing && ix->ev_pending.size() < 4096;
+    if (timed) {
+        if (!ix->ev_free.empty()) {
+            ev = ix->ev_free.back();
+            ix->ev_free.pop_back();
+        } else {
+            OTTER_HIP_TRY(hipEventCreate(&ev.first));
+            OTTER_HIP_TRY(hipEventCreate(&ev.second));
+        }
+        OTTER_HIP_TRY(hipEventRecord(ev.first, st));
+    }
     cfg.launch(sa, qtiles * strips, cfg.lds, st);
     OTTER_HIP_TRY(hipGetLastError());
+    if (timed) {
+        OTTER_HIP_TRY(hipEventRecord(ev.second, st));
+        ix->ev_pending.push_back(ev);
+    }
 
     // merge levels: S strips -> 1
     const int fan = std::max(2, MAX_SELECT / k);
@@ -751,9 +821,34 @@ int otter_index_set_id_base(otter_index* ix, int64_t id_base) {
     return OTTER_OK;
 }
 
+int otter_index_set_timing(otter_index* ix, int enable) {
+    if (!ix) return set_err(OTTER_EINVAL, "set_timing: index is NULL");
+    ix->timing = enable != 0;
+    return OTTER_OK;
+}
+
+int otter_index_timing(otter_index* ix, double* scan_ms, int64_t* scan_launches) {
+    if (!ix || !scan_ms || !scan_launches) return set_err(OTTER_EINVAL, "timing: NULL argument");
+    DeviceGuard g(ix->device);
+    double total = 0.0;
+    for (auto& ev : ix->ev_pending) {
+        OTTER_HIP_TRY(hipEventSynchronize(ev.second));
+        float ms = 0.f;
+        OTTER_HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+        total += ms;
+        ix->ev_free.push_back(ev);
+    }
+    *scan_ms = total;
+    *scan_launches = (int64_t)ix->ev_pending.size();
+    ix->ev_pending.clear();
+    return OTTER_OK;
+}
+
 void otter_index_destroy(otter_index* ix) {
     if (!ix) return;
     DeviceGuard g(ix->device);
+    for (auto& ev : ix->ev_pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& ev : ix->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ix->x) (void)hipFree(ix->x);
     ix->qpad.release();
     ix->cand.release();

@@ -119,6 +119,17 @@ class IndexFlatIP:
     def reset(self):
         _lib.check(self._lib.otter_index_reset(self._h), "otter_index_reset")
 
+    # -- measurement hook (bench.py): HIP-event time of the scan kernel
+    def set_timing(self, enable=True):
+        _lib.check(self._lib.otter_index_set_timing(self._h, 1 if enable else 0), "otter_index_set_timing")
+
+    def timing(self):
+        """(summed scan-kernel milliseconds, launches) since the previous call."""
+        ms = ctypes.c_double(0.0)
+        n = ctypes.c_int64(0)
+        _lib.check(self._lib.otter_index_timing(self._h, ctypes.byref(ms), ctypes.byref(n)), "otter_index_timing")
+        return ms.value, n.value
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.otter_index_destroy(self._h)
