@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libotter_hip.so")
+LIB_PATH = os.environ.get("OTTER_LIB", os.path.join(_PKG, "libotter_hip.so"))
 
 OTTER_OK = 0
 OTTER_EINVAL, OTTER_ENOMEM, OTTER_EHIP, OTTER_ESTATE, OTTER_ENOTIMPL = -1, -2, -3, -4, -5

@@ -36,8 +36,10 @@ typedef uint32_t u32;
 #define AS1 __attribute__((address_space(1)))
 #define AS3 __attribute__((address_space(3)))
 
-constexpr int BK = 64;            // floats of k per LDS stage (256 B per row)
-constexpr int ROW_BYTES = BK * 4;  // 256
+#ifndef SCAN_G0
+#define SCAN_G0 4                 // k-groups (of 8) of a stage over which its LDS-DMA pieces are issued
+#endif
+constexpr int LD_ALIGN = 64;       // corpus / query row length is padded to a multiple of this
 constexpr int NTHREADS = 256;      // 4 waves, one per SIMD
 
 // monotone map float -> u32 (larger float <=> larger key); -0 is folded into +0
@@ -95,7 +97,18 @@ struct ScanArgs {
     int qtiles;         // nq_pad / BQ
     int strips;         // S
     int total_tiles;    // ceil(n / BM)
+    u64* dbg;           // SCAN_DIAG builds only: per-wave cycle sums {total, stage wait, epilogue, stages}
 };
+
+#ifdef SCAN_DIAG
+__device__ __forceinline__ u64 stamp() {
+    u64 t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#endif
 
 // One wavefront selects the k largest of the n (<= 64*EPL) composites at `base`,
 // moves them to base[0..k) and returns the k-th largest.  Radix select, one bit
@@ -130,8 +143,13 @@ __device__ __forceinline__ u64 wave_compact(u64* base, int n, int k, int lane) {
 }
 
 // WM x WQ waves; each wave owns (MB*32) corpus rows x (QB*32) queries of the tile.
-template <int WM, int WQ, int MB, int QB, int NSTAGE, int EPL>
+// BK floats of k per LDS stage (64: 256-B rows, 32: 128-B rows); NSTAGE ring slots.
+template <int WM, int WQ, int MB, int QB, int BK, int NSTAGE, int EPL>
 __global__ __launch_bounds__(WM * WQ * 64, WM * WQ / 4) void scan_kernel(ScanArgs a) {
+    static_assert(BK == 64 || BK == 32, "stage depth");
+    constexpr int ROW_BYTES = BK * 4;
+    constexpr int CH = BK / 4;           // 16-B chunks per row
+    constexpr int RPI = 64 / CH;         // rows per LDS-DMA instruction (1 KiB)
     constexpr int NW = WM * WQ;          // waves per workgroup (4: one per SIMD, 8: two)
     constexpr int NT = NW * 64;
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -141,10 +159,11 @@ __global__ __launch_bounds__(WM * WQ * 64, WM * WQ / 4) void scan_kernel(ScanArg
     constexpr int A_BYTES = BM * ROW_BYTES;
     constexpr int B_BYTES = BQ * ROW_BYTES;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int A_INSTR = BM / 4 / NW;  // LDS-DMA instructions per wave per stage (1 KiB = 4 rows each)
-    constexpr int B_INSTR = BQ / 4 / NW;
-    static_assert(A_INSTR * 4 * NW == BM && B_INSTR * 4 * NW == BQ, "tile rows must split over the waves");
+    constexpr int A_INSTR = BM / RPI / NW;  // LDS-DMA instructions per wave per stage (1 KiB each)
+    constexpr int B_INSTR = BQ / RPI / NW;
+    static_assert(A_INSTR * RPI * NW == BM && B_INSTR * RPI * NW == BQ, "tile rows must split over the waves");
     constexpr int IPS = A_INSTR + B_INSTR;
+    constexpr int G0 = SCAN_G0 < BK / 8 ? SCAN_G0 : BK / 8;  // k-groups over which a stage's DMA is issued
     static_assert(CAP - BM >= 128, "candidate buffer too small");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -184,23 +203,27 @@ __global__ __launch_bounds__(WM * WQ * 64, WM * WQ / 4) void scan_kernel(ScanArg
     u64* candBase = a.cand + ((size_t)strip * a.nq_pad + q0) * CAP;
 
     // ---- LDS-DMA producer: one k-stage of one tile into a ring slot ----
-    // LDS image of a stage: [row][16 chunks of 16 B]; chunk p of row r holds the
-    // global chunk p ^ (r & 15) (swizzle on the SOURCE address; the DMA writes linearly).
+    // LDS image of a stage: [row][CH chunks of 16 B]; chunk p of row r holds the global
+    // chunk p ^ swz(r) (swizzle on the SOURCE address; the DMA writes linearly), swz chosen
+    // so that the 16 rows one ds_read_b128 lane group touches fall on 16 distinct 16-B slots
+    // of the 256-B bank row: r & 15 for 256-B rows, (r >> 1) & 7 for 128-B rows.
     // A stage is IPS wave-instructions of 1 KiB (4 rows) per wave.  Per-lane byte offsets
     // are fixed for the whole kernel; the corpus allocation is padded to whole tiles, so
     // no row clamp is needed (rows >= n are masked in the epilogue).
-    const int dma_r = lane >> 4;   // row within the 4-row group of one instruction
-    const int dma_p = lane & 15;   // LDS chunk position
+    const int dma_r = lane / CH;   // row within the row group of one instruction
+    const int dma_p = lane % CH;   // LDS chunk position
+    auto swz = [](int r) { return CH == 16 ? (r & 15) : ((r >> 1) & 7); };
     const u32 lds0 = (u32)(uintptr_t)(AS3 char*)smem;
     u32 voff[IPS];
 #pragma unroll
     for (int t = 0; t < IPS; ++t) {
         const int i = (t < A_INSTR ? t : t - A_INSTR) * NW + wave;
-        const int r = 4 * i + dma_r;
-        voff[t] = ((u32)r * (u32)a.ld + (u32)((dma_p ^ (r & 15)) << 2)) * 4u;
+        const int r = RPI * i + dma_r;
+        voff[t] = ((u32)r * (u32)a.ld + (u32)((dma_p ^ swz(r)) << 2)) * 4u;
     }
     const float* gQ = a.Q + (size_t)q0 * a.ld;
 
+    long long f = 0;   // flat index of the stage being consumed
     // the stage being produced: scalar bases + ring slot; pieces are issued one by one
     int it_tile = t0, it_ks = 0;
     bool pr_have = false;
@@ -217,7 +240,11 @@ __global__ __launch_bounds__(WM * WQ * 64, WM * WQ / 4) void scan_kernel(ScanArg
         }
     };
     auto produce_piece = [&](int t) {   // t in [0, IPS), compile-time after unrolling
+#ifdef SCAN_ABL_NODMA
+        if (pr_have && f < 0) {   // timing-only ablation: never issue (results are garbage)
+#else
         if (pr_have) {
+#endif
             if (t < A_INSTR) dma16s(pr_gA, voff[t], pr_lds + (t * NW + wave) * 1024);
             else dma16s(pr_gB, voff[t], pr_lds + A_BYTES + ((t - A_INSTR) * NW + wave) * 1024);
         }
@@ -252,7 +279,10 @@ __global__ __launch_bounds__(WM * WQ * 64, WM * WQ / 4) void scan_kernel(ScanArg
     };
 
     const long long total_stages = (long long)(t1 - t0) * KS;
-    long long f = 0;
+#ifdef SCAN_DIAG
+    u64 dg_wait = 0, dg_epi = 0;
+    const u64 dg_t0 = stamp();
+#endif
 
     // prologue: fill NSTAGE-1 ring slots
 #pragma unroll
@@ -264,15 +294,21 @@ __global__ __launch_bounds__(WM * WQ * 64, WM * WQ / 4) void scan_kernel(ScanArg
 
     int slot = 0;
     const int h = lane >> 5;
-    const int l15 = lane & 15;
     const int l31 = lane & 31;
+    const int lswz = swz(l31);     // block row offsets are multiples of 32: swz(row) == swz(lane & 31)
 
     for (int tile = t0; tile < t1; ++tile) {
         for (int ks = 0; ks < KS; ++ks, ++f) {
+#ifdef SCAN_DIAG
+            const u64 dg_a = stamp();
+#endif
             // stage f has landed once at most (NSTAGE-2) younger stages are outstanding
             if (total_stages - 1 - f >= NSTAGE - 2) wait_vmcnt<(NSTAGE - 2) * IPS>();
             else wait_vmcnt<0>();
             wg_barrier();
+#ifdef SCAN_DIAG
+            dg_wait += stamp() - dg_a;
+#endif
             if (ks == 0 && tile > t0) {
                 // every wave has finished the previous tile's epilogue
                 if (__builtin_amdgcn_readfirstlane(*sFlag)) compact_pass(false);  // LDS read, reloaded after the barrier
@@ -282,7 +318,7 @@ __global__ __launch_bounds__(WM * WQ * 64, WM * WQ / 4) void scan_kernel(ScanArg
             // fragments of k-group j: 16 B per lane = 4 MFMA k-steps (k = 8j + 4h + t)
             float4 af[2][MB], bf[2][QB];
             auto load_frags = [&](int j, int buf) {
-                const int coff = ((2 * j + h) ^ l15) << 4;
+                const int coff = ((2 * j + h) ^ lswz) << 4;
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
                     af[buf][m] =
@@ -301,7 +337,8 @@ __global__ __launch_bounds__(WM * WQ * 64, WM * WQ / 4) void scan_kernel(ScanArg
                 const int cb = j & 1;
                 if (j + 1 < BK / 8) load_frags(j + 1, cb ^ 1);  // register double buffer
 #pragma unroll
-                for (int t = j; t < IPS; t += BK / 8) produce_piece(t);
+                for (int t = j; t < IPS; t += G0)
+                    if (j < G0) produce_piece(t);
                 // keep the reads of group j+1 ahead of group j's MFMAs (hipcc sinks them otherwise)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -318,30 +355,55 @@ __global__ __launch_bounds__(WM * WQ * 64, WM * WQ / 4) void scan_kernel(ScanArg
         }
 
         // ---- epilogue of one tile: threshold filter, append survivors ----
+#ifdef SCAN_DIAG
+        const u64 dg_e = stamp();
+#endif
         const long long row0 = (long long)tile * BM;
 #pragma unroll
         for (int q = 0; q < QB; ++q) {
             const int ql = (wq * QB + q) * 32 + l31;
             const u32 thr = sThr[ql];
+            // float image of the threshold for the cheap pre-test (thr == 0: accept everything)
+            const float thrf = key2f(thr);
             u64* qbuf = candBase + (size_t)ql * CAP;
 #pragma unroll
             for (int m = 0; m < MB; ++m) {
+                // after warm-up almost no score beats the running k-th best: test the block's
+                // maximum first (8 v_max3) and only then look at the 16 scores one by one
+                float mx = fmaxf(acc[m][q][0], acc[m][q][1]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rt = (wm * MB + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const long long grow = row0 + rt;
-                    const u32 key = f2key(acc[m][q][r]);
-                    if (key > thr && grow < a.n) {
-                        const u32 pos = atomicAdd(&sCnt[ql], 1u);
-                        if (pos < (u32)CAP) qbuf[pos] = ((u64)key << 32) | (u64)(0xFFFFFFFFu - (u32)grow);
-                        if (pos + 1 > (u32)(CAP - BM)) *sFlag = 1;
+                for (int r = 2; r < 16; ++r) mx = fmaxf(mx, acc[m][q][r]);
+                if (thr == 0u || mx > thrf || mx != mx) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rt = (wm * MB + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const long long grow = row0 + rt;
+                        const u32 key = f2key(acc[m][q][r]);
+                        if (key > thr && grow < a.n) {
+                            const u32 pos = atomicAdd(&sCnt[ql], 1u);
+                            if (pos < (u32)CAP) qbuf[pos] = ((u64)key << 32) | (u64)(0xFFFFFFFFu - (u32)grow);
+                            if (pos + 1 > (u32)(CAP - BM)) *sFlag = 1;
+                        }
                     }
-                    acc[m][q][r] = 0.0f;
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.0f;
             }
         }
+#ifdef SCAN_DIAG
+        dg_epi += stamp() - dg_e;
+#endif
     }
 
+#ifdef SCAN_DIAG
+    if (a.dbg && lane == 0) {
+        u64* o = a.dbg + ((size_t)blockIdx.x * NW + wave) * 4;
+        o[0] = stamp() - dg_t0;
+        o[1] = dg_wait;
+        o[2] = dg_epi;
+        o[3] = (u64)total_stages;
+    }
+#endif
     // ---- end of strip: leave at most k composites per query, publish counts ----
     compact_pass(true);
     for (int i = tid; i < BQ; i += NT) a.cnt[(size_t)strip * a.nq_pad + q0 + i] = sCnt[i];
@@ -495,9 +557,9 @@ struct ScanCfg {
     void (*launch)(const ScanArgs&, int grid, size_t lds, hipStream_t);
 };
 
-template <int WM, int WQ, int MB, int QB, int NSTAGE, int EPL>
+template <int WM, int WQ, int MB, int QB, int BK, int NSTAGE, int EPL>
 void launch_scan(const ScanArgs& a, int grid, size_t lds, hipStream_t st) {
-    auto kern = scan_kernel<WM, WQ, MB, QB, NSTAGE, EPL>;
+    auto kern = scan_kernel<WM, WQ, MB, QB, BK, NSTAGE, EPL>;
     static bool attr_set[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -509,33 +571,39 @@ void launch_scan(const ScanArgs& a, int grid, size_t lds, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WQ * 64), lds, st, a);
 }
 
-template <int WM, int WQ, int MB, int QB, int NSTAGE, int EPL>
+template <int WM, int WQ, int MB, int QB, int BK, int NSTAGE, int EPL>
 ScanCfg make_cfg() {
     constexpr int BM = WM * MB * 32, BQ = WQ * QB * 32;
     ScanCfg c;
     c.bm = BM;
     c.bq = BQ;
     c.cap = EPL * 64;
-    c.lds = (size_t)NSTAGE * (BM + BQ) * ROW_BYTES + (size_t)(2 * BQ + 4) * sizeof(u32);
-    c.launch = &launch_scan<WM, WQ, MB, QB, NSTAGE, EPL>;
+    c.lds = (size_t)NSTAGE * (BM + BQ) * BK * 4 + (size_t)(2 * BQ + 4) * sizeof(u32);
+    c.launch = &launch_scan<WM, WQ, MB, QB, BK, NSTAGE, EPL>;
     return c;
 }
 
 // query-tile shapes: S (<=32 queries, HBM-bound), M (<=64), L (MFMA-bound)
+// EPL = candidate slots per lane of the compaction (buffer capacity 64*EPL): the k class's
+// base (2 * kmax + 128, i.e. room for kmax new survivors between compactions at 128-row
+// tiles) plus 2 per extra 128 rows of the tile.
 template <int EPL>
 ScanCfg pick_shape(long long nq) {
-    if (nq <= 32) return make_cfg<4, 1, 1, 1, 3, EPL>();
-    if (nq <= 64) return make_cfg<4, 1, 1, 2, 3, EPL>();
-    static const bool w4 = getenv("OTTER_SCAN_W4") != nullptr;   // A/B switch for tuning runs
-    if (w4) return make_cfg<2, 2, 2, 2, 2, EPL>();
-    return make_cfg<2, 4, 2, 1, 2, EPL>();
+    if (nq <= 32) return make_cfg<4, 1, 1, 1, 64, 3, EPL>();
+    if (nq <= 64) return make_cfg<4, 1, 1, 2, 64, 3, EPL>();
+    static const char* v = getenv("OTTER_SCAN_VARIANT");   // A/B switch for tuning runs
+    if (v && v[0] == 'a') return make_cfg<2, 2, 2, 2, 64, 2, EPL>();      // 128x128, 4 waves, 2 x 64 KB
+    if (v && v[0] == 'b') return make_cfg<2, 4, 2, 1, 64, 2, EPL>();      // 128x128, 8 waves, 2 x 64 KB
+    if (v && v[0] == 'c') return make_cfg<2, 4, 2, 1, 32, 4, EPL>();      // 128x128, 8 waves, 4 x 32 KB
+    if (EPL >= 64) return make_cfg<2, 4, 2, 1, 32, 4, EPL>();             // k > 1024: keep registers for the select
+    return make_cfg<4, 2, 2, 2, 32, 3, (EPL >= 64 ? 6 : EPL + 2)>();      // 256x128, 8 waves, 3 x 48 KB
 }
 
 int pick_cfg(long long nq, int k, ScanCfg* out) {
     if (k <= 128) *out = pick_shape<6>(nq);
     else if (k <= 512) *out = pick_shape<18>(nq);
     else if (k <= 1024) *out = pick_shape<34>(nq);
-    else if (k <= 2048) *out = pick_shape<66>(nq);
+    else if (k <= 2048) *out = pick_shape<64>(nq);
     else return set_err(OTTER_EINVAL, "search: k=%d exceeds OTTER_MAX_K=%d", k, OTTER_MAX_K);
     return OTTER_OK;
 }
@@ -561,11 +629,11 @@ namespace {
 
 int index_reserve_rows(otter_index* ix, long long need_rows, hipStream_t st) {
     if (need_rows <= ix->cap_rows) return OTTER_OK;
-    // capacity is kept a multiple of the scan tile (128 rows): the kernel reads whole tiles
+    // capacity is kept a multiple of the largest scan tile (256 rows): the kernel reads whole tiles
     // and masks rows >= n, so the tail of the last tile must be addressable
-    need_rows = round_up64(need_rows, 128);
+    need_rows = round_up64(need_rows, 256);
     long long want = ix->cap_rows == 0 ? need_rows : std::max(need_rows, ix->cap_rows + ix->cap_rows / 2);
-    want = round_up64(want, 128);
+    want = round_up64(want, 256);
     float* nx = nullptr;
     hipError_t e = hipMalloc((void**)&nx, (size_t)want * ix->ld * sizeof(float));
     if (e != hipSuccess && want > need_rows) {
@@ -623,6 +691,14 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
     sa.qtiles = qtiles;
     sa.strips = strips;
     sa.total_tiles = total_tiles;
+    sa.dbg = nullptr;
+#ifdef SCAN_DIAG
+    static otter::DevBuf dbgbuf;
+    const size_t dbg_n = (size_t)qtiles * strips * 8 * 4;
+    if ((rc = dbgbuf.reserve(dbg_n * sizeof(u64)))) return rc;
+    OTTER_HIP_TRY(hipMemsetAsync(dbgbuf.p, 0, dbg_n * sizeof(u64), st));
+    sa.dbg = (u64*)dbgbuf.p;
+#endif
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     const bool timed = ix->timing && ix->ev_pending.size() < 4096;
     if (timed) {
@@ -641,6 +717,23 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
         OTTER_HIP_TRY(hipEventRecord(ev.second, st));
         ix->ev_pending.push_back(ev);
     }
+#ifdef SCAN_DIAG
+    {
+        std::vector<u64> hbuf(dbg_n);
+        OTTER_HIP_TRY(hipStreamSynchronize(st));
+        OTTER_HIP_TRY(hipMemcpy(hbuf.data(), dbgbuf.p, dbg_n * sizeof(u64), hipMemcpyDeviceToHost));
+        double tot = 0, wait = 0, epi = 0, stages = 0, nwv = 0, mx = 0;
+        for (size_t i = 0; i < dbg_n; i += 4) {
+            if (hbuf[i] == 0) continue;
+            tot += hbuf[i]; wait += hbuf[i + 1]; epi += hbuf[i + 2]; stages += hbuf[i + 3]; nwv += 1;
+            mx = std::max(mx, (double)hbuf[i]);
+        }
+        if (nwv > 0)
+            fprintf(stderr, "[scan diag] waves=%.0f mean cycles/wave: total %.0f (max %.0f) stage-wait %.0f epilogue %.0f; "
+                            "per stage: total %.0f wait %.0f\n",
+                    nwv, tot / nwv, mx, wait / nwv, epi / nwv, tot / stages, wait / stages);
+    }
+#endif
 
     // merge levels: S strips -> 1
     const int fan = std::max(2, MAX_SELECT / k);
@@ -724,7 +817,7 @@ int otter_index_create(int d, int dtype, int device, otter_index** out) {
     otter_index* ix = new (std::nothrow) otter_index();
     if (!ix) return set_err(OTTER_ENOMEM, "index_create: host allocation failed");
     ix->d = d;
-    ix->ld = round_up(d, BK);
+    ix->ld = round_up(d, LD_ALIGN);
     ix->dtype = dtype;
     ix->device = device;
     ix->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
