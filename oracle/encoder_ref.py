@@ -1,0 +1,221 @@
+"""oracle/encoder_ref.py — CPU restatement (plain torch, fp32/fp64) of OTTeR's bi-encoder forward.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke(), bench.py's cpu_baseline
+leg and oracle/gen_encoder_goldens.py; never by otter_amd/.
+
+Pinned: oracle/gen_encoder_goldens.py runs the REFERENCE classes themselves in the build
+container (imported from /root/reference with the two absent modules stubbed)
+on the same seeded weights and inputs, checks this restatement against them, and commits
+the reference's outputs under tests/golden/encoder_*.npz.  tests/test_encoder_oracle.py
+re-checks this file against those fixtures on every run.
+
+What is restated (reference file:line):
+  * pooling_masked_part                      retrieval/models/tb_retriever.py:42-58
+  * SingleEncoderThreeCatPool.encode_seq     retrieval/models/tb_retriever.py:172-195
+    (= encode_q with shared_encoder,         :197-227; Roberta subclass forward :256-261)
+  * SingleEncoder.encode_seq (one vector)    retrieval/models/retriever.py:270-286, :340-345
+  * the HF AutoModel forward it calls (:180-185): RoBERTa/BERT-base post-LN encoder,
+    transformers/models/roberta/modeling_roberta.py (embeddings :56-155 incl. the
+    cumulative-sum position ids :142-155; self-attention :157-184; layer :186-399) and
+    the BERT equivalents (arange positions, token types).
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+POOLS = ("mean", "sum", "max", "cls", "first")
+
+
+def make_config(family="roberta", layers=12, vocab_size=None, hidden=768, heads=12, inter=3072,
+                three_cat=True, no_proj=True, part_pooling="first"):
+    """Shape/config dict with the fields of HF's RobertaConfig/BertConfig that the forward reads."""
+    if family == "roberta":
+        cfg = dict(vocab_size=vocab_size or 50265, max_position_embeddings=514, type_vocab_size=1,
+                   pad_token_id=1, layer_norm_eps=1e-5, position_mode="roberta")
+    elif family == "bert":
+        cfg = dict(vocab_size=vocab_size or 30522, max_position_embeddings=512, type_vocab_size=2,
+                   pad_token_id=0, layer_norm_eps=1e-12, position_mode="bert")
+    else:
+        raise ValueError(family)
+    cfg.update(family=family, hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads,
+               intermediate_size=inter, three_cat=three_cat, no_proj=no_proj, part_pooling=part_pooling)
+    return cfg
+
+
+def make_state_dict(cfg, seed):
+    """Seeded weights under the reference wrapper's state_dict key names (utils.py:12-28 loads
+    exactly these): 'encoder.embeddings.*', 'encoder.encoder.layer.N.*', 'encoder.pooler.*',
+    'project.0.*' (Linear), 'project.1.*' (LayerNorm).  numpy RandomState (frozen legacy stream);
+    LayerNorm gamma/beta are non-trivial on purpose (HF's default 1/0 hides scaling bugs)."""
+    rs = np.random.RandomState(seed)
+    H, I = cfg["hidden_size"], cfg["intermediate_size"]
+
+    def nrm(shape, std):
+        return torch.from_numpy((rs.standard_normal(size=shape) * std).astype(np.float32))
+
+    def ln(prefix, sd):
+        sd[prefix + ".weight"] = 1.0 + nrm((H,), 0.1)
+        sd[prefix + ".bias"] = nrm((H,), 0.1)
+
+    sd = OrderedDict()
+    e = "encoder.embeddings."
+    sd[e + "word_embeddings.weight"] = nrm((cfg["vocab_size"], H), 0.05)
+    sd[e + "position_embeddings.weight"] = nrm((cfg["max_position_embeddings"], H), 0.05)
+    sd[e + "token_type_embeddings.weight"] = nrm((cfg["type_vocab_size"], H), 0.05)
+    ln(e + "LayerNorm", sd)
+    for i in range(cfg["num_hidden_layers"]):
+        p = "encoder.encoder.layer.%d." % i
+        for name in ("attention.self.query", "attention.self.key", "attention.self.value",
+                     "attention.output.dense"):
+            sd[p + name + ".weight"] = nrm((H, H), 0.04)
+            sd[p + name + ".bias"] = nrm((H,), 0.02)
+        ln(p + "attention.output.LayerNorm", sd)
+        sd[p + "intermediate.dense.weight"] = nrm((I, H), 0.04)
+        sd[p + "intermediate.dense.bias"] = nrm((I,), 0.02)
+        sd[p + "output.dense.weight"] = nrm((H, I), 0.03)
+        sd[p + "output.dense.bias"] = nrm((H,), 0.02)
+        ln(p + "output.LayerNorm", sd)
+    sd["encoder.pooler.dense.weight"] = nrm((H, H), 0.04)   # present in checkpoints, unused by the path
+    sd["encoder.pooler.dense.bias"] = nrm((H,), 0.02)
+    sd["project.0.weight"] = nrm((H, H), 0.04)
+    sd["project.0.bias"] = nrm((H,), 0.02)
+    ln("project.1", sd)
+    return sd
+
+
+def make_batch(cfg, B, L, seed, ragged=True, question=False):
+    """Synthetic batch dict in the layout of em_collate_bert (retrieval/data/encode_datasets.py:393-417):
+    int64 [B, L] input_ids / input_mask / part2_mask / part3_mask (+ input_type_ids for BERT), built
+    by the mask rule of retrieval/data/tr_dataset.py:117-153 on a fake '<s> A </s></s> B </s> <pad>*'
+    token layout (question=True: single segment, part3 = part2, :125-133)."""
+    rs = np.random.RandomState(seed)
+    pad = cfg["pad_token_id"]
+    rob = cfg["family"] == "roberta"
+    cls_id, sep_id = (0, 2) if rob else (101, 102)
+    lo = 3 if rob else 1000
+    ids = np.full((B, L), pad, dtype=np.int64)
+    mask = np.zeros((B, L), dtype=np.int64)
+    p2 = np.zeros((B, L), dtype=np.int64)
+    p3 = np.zeros((B, L), dtype=np.int64)
+    tt = np.zeros((B, L), dtype=np.int64)
+    for b in range(B):
+        n = L if (not ragged or b == 0) else int(rs.randint(max(8, L // 4), L + 1))
+        toks = rs.randint(lo, cfg["vocab_size"], size=n)
+        toks[0] = cls_id
+        if question:
+            toks[n - 1] = sep_id
+            p2[b, 1:n - 1] = 1
+            p3[b] = p2[b]
+        else:
+            a_end = int(rs.randint(2, max(3, n // 3)))          # first separator
+            toks[a_end] = sep_id
+            nsep = 2 if rob else 1                               # roberta: </s></s>
+            if rob:
+                toks[a_end + 1] = sep_id
+            toks[n - 1] = sep_id
+            p2[b, 1:a_end] = 1
+            p3[b, a_end + nsep:n - 1] = 1
+            tt[b, a_end + 1:n] = 0 if rob else 1
+        ids[b, :n] = toks
+        mask[b, :n] = 1
+    batch = {"input_ids": torch.from_numpy(ids), "input_mask": torch.from_numpy(mask),
+             "part2_mask": torch.from_numpy(p2), "part3_mask": torch.from_numpy(p3)}
+    if not rob:
+        batch["input_type_ids"] = torch.from_numpy(tt)
+    return batch
+
+
+def pooling_masked_part(hidden, mask, method="mean"):
+    """tb_retriever.py:42-58, with the B=1 `.squeeze()` accident removed (the reference then
+    fails in torch.cat; the build returns [1, H])."""
+    maskf = mask.to(hidden.dtype)
+    if method == "mean":
+        return (hidden * maskf.unsqueeze(2)).sum(1) / maskf.sum(1, keepdim=True)
+    if method == "sum":
+        return (hidden * maskf.unsqueeze(2)).sum(1)
+    if method == "max":
+        return (hidden + ((1 - maskf) * -1e5).unsqueeze(2)).max(dim=1)[0]
+    if method == "first":
+        L = mask.shape[1]
+        tmp = mask * torch.arange(L, 0, -1, device=mask.device)
+        index = torch.argmax(tmp, 1)                      # first 1 of the mask; 0 for an empty mask
+        return hidden[torch.arange(hidden.shape[0]), index]
+    return hidden[:, 0, :]                                # 'cls' and anything else
+
+
+class EncoderRef:
+    """Functional restatement; `dtype` torch.float32 (parity reference) or float64 (arbiter)."""
+
+    def __init__(self, cfg, state_dict, dtype=torch.float32):
+        self.cfg = dict(cfg)
+        self.dtype = dtype
+        self.w = {k: v.to(dtype) for k, v in state_dict.items()}
+
+    # -- HF embeddings (modeling_roberta.py:56-155 / modeling_bert.py)
+    def embed(self, ids, type_ids=None):
+        c, w = self.cfg, self.w
+        e = "encoder.embeddings."
+        if c["position_mode"] == "roberta":
+            m = (ids != c["pad_token_id"]).long()
+            pos = torch.cumsum(m, dim=1) * m + c["pad_token_id"]
+        else:
+            pos = torch.arange(ids.shape[1]).unsqueeze(0).expand_as(ids)
+        if type_ids is None:
+            type_ids = torch.zeros_like(ids)
+        x = w[e + "word_embeddings.weight"][ids] + w[e + "position_embeddings.weight"][pos] + \
+            w[e + "token_type_embeddings.weight"][type_ids]
+        return torch.nn.functional.layer_norm(x, (c["hidden_size"],), w[e + "LayerNorm.weight"],
+                                              w[e + "LayerNorm.bias"], c["layer_norm_eps"])
+
+    def layer(self, x, i, key_bias):
+        c, w = self.cfg, self.w
+        p = "encoder.encoder.layer.%d." % i
+        B, L, H = x.shape
+        nh = c["num_attention_heads"]
+        dh = H // nh
+        lin = torch.nn.functional.linear
+
+        def heads(t):
+            return t.view(B, L, nh, dh).permute(0, 2, 1, 3)
+
+        q = heads(lin(x, w[p + "attention.self.query.weight"], w[p + "attention.self.query.bias"]))
+        k = heads(lin(x, w[p + "attention.self.key.weight"], w[p + "attention.self.key.bias"]))
+        v = heads(lin(x, w[p + "attention.self.value.weight"], w[p + "attention.self.value.bias"]))
+        s = q @ k.transpose(-1, -2) * (dh ** -0.5) + key_bias           # [B, nh, L, L]
+        a = torch.softmax(s, dim=-1) @ v
+        a = a.permute(0, 2, 1, 3).reshape(B, L, H)
+        a = lin(a, w[p + "attention.output.dense.weight"], w[p + "attention.output.dense.bias"])
+        x = torch.nn.functional.layer_norm(a + x, (H,), w[p + "attention.output.LayerNorm.weight"],
+                                           w[p + "attention.output.LayerNorm.bias"], c["layer_norm_eps"])
+        f = lin(x, w[p + "intermediate.dense.weight"], w[p + "intermediate.dense.bias"])
+        f = torch.nn.functional.gelu(f)                                  # exact erf form
+        f = lin(f, w[p + "output.dense.weight"], w[p + "output.dense.bias"])
+        return torch.nn.functional.layer_norm(f + x, (H,), w[p + "output.LayerNorm.weight"],
+                                              w[p + "output.LayerNorm.bias"], c["layer_norm_eps"])
+
+    def hidden(self, ids, mask, type_ids=None, n_layers=None):
+        """last_hidden_state after n_layers layers (None = all), [B, L, H]."""
+        n = self.cfg["num_hidden_layers"] if n_layers is None else n_layers
+        x = self.embed(ids, type_ids)
+        key_bias = ((1 - mask.to(self.dtype)) * torch.finfo(self.dtype).min)[:, None, None, :]
+        for i in range(n):
+            x = self.layer(x, i, key_bias)
+        return x
+
+    def forward(self, batch):
+        """model(batch) -> {'embed': [B, D]} (tb_retriever.py:256-261 / retriever.py:340-345)."""
+        c, w = self.cfg, self.w
+        h = self.hidden(batch["input_ids"], batch["input_mask"], batch.get("input_type_ids"))
+        part1 = h[:, 0, :]
+        if not c["no_proj"]:
+            part1 = torch.nn.functional.linear(part1, w["project.0.weight"], w["project.0.bias"])
+            part1 = torch.nn.functional.layer_norm(part1, (c["hidden_size"],), w["project.1.weight"],
+                                                   w["project.1.bias"], c["layer_norm_eps"])
+        if not c["three_cat"]:
+            return {"embed": part1}
+        part2 = pooling_masked_part(h, batch["part2_mask"], c["part_pooling"])
+        part3 = pooling_masked_part(h, batch["part3_mask"], c["part_pooling"])
+        return {"embed": torch.cat([part1, part2, part3], dim=1)}
+
+    __call__ = forward

@@ -1,13 +1,927 @@
-// encoder.hip — placeholder entry points (replaced by the real encoder below in this round)
+// encoder.hip — BERT/RoBERTa-base bi-encoder forward on gfx950 (fp32 parity path and bf16
+// throughput path share every kernel through a storage-type template).
+//
+// Replaces `model(batch)['embed']` of the reference's encoder classes
+// (retrieval/models/tb_retriever.py:150-261, retrieval/models/retriever.py:249-345) including
+// the HF AutoModel forward they call (tb_retriever.py:180-185).
+//
+// Activations live in HBM as row-major [M_pad, width] in the compute type T (float or bf16),
+// M = B*L tokens, M_pad = M rounded up to the 256-row GEMM tile (+64 rows of slack for the
+// attention key tiles); padding rows are zero and are never written with non-finite values.
+//
+// Per layer:  QKV = X Wqkv^T + b                (gemm, 256x256 tile, LDS-DMA ring, MFMA)
+//             CTX = softmax(Q K^T / 8 + mask) V  (flash-style, scores never leave registers)
+//             T1  = CTX Wo^T + b + X ; X1 = LN(T1)
+//             MID = gelu(X1 W1^T + b)
+//             T2  = MID W2^T + b + X1 ; X = LN(T2)
+#include <math.h>
+#include <stdlib.h>
+
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
 #include "otter_common.h"
+#include "otter_device.h"
+
+namespace {
+
 using namespace otter;
-struct otter_encoder { int dummy; };
-extern "C" {
-int otter_encoder_create(const otter_encoder_cfg*, int, otter_encoder** out) { if (out) *out = nullptr; return set_err(OTTER_ENOTIMPL, "encoder not built yet"); }
-int otter_encoder_set_weight(otter_encoder*, const char*, const float*, const int64_t*, int) { return set_err(OTTER_ENOTIMPL, "encoder not built yet"); }
-int otter_encoder_finalize(otter_encoder*, int) { return set_err(OTTER_ENOTIMPL, "encoder not built yet"); }
-int otter_encoder_forward(otter_encoder*, const int64_t*, const int64_t*, const int64_t*, const int64_t*, const int64_t*, int, int, float*, void*) { return set_err(OTTER_ENOTIMPL, "encoder not built yet"); }
-int otter_encoder_forward_hidden(otter_encoder*, const int64_t*, const int64_t*, const int64_t*, int, int, int, float*, void*) { return set_err(OTTER_ENOTIMPL, "encoder not built yet"); }
-int otter_encoder_out_dim(const otter_encoder*) { return -1; }
-void otter_encoder_destroy(otter_encoder*) {}
+
+// ------------------------------------------------------------------ GEMM (NT)
+// C[M_pad, N] = A[M_pad, K] * W[N, K]^T (+ bias[N]) (+ gelu | + R[M_pad, N]); fp32 accumulate.
+// 256 x 256 tile, 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = 4 x 2 MFMA blocks of 32 x 32.
+// LDS stage: 128-byte rows (32 floats / 64 bf16 of k) of the 256 A rows and 256 W rows = 64 KB,
+// two stages.  Fragment reads are 16 B per lane (chunk 2j + h of the row): for fp32 that is four
+// k-steps of v_mfma_f32_32x32x2_f32, for bf16 one v_mfma_f32_32x32x16_bf16.
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2 };
+
+struct GemmArgs {
+    const void* A;
+    const void* W;
+    const float* bias;
+    const void* R;
+    void* C;
+    int tiles_m, tiles_n;
+    int K;              // elements
+    int lda, ldw, ldc;  // elements
+};
+
+template <typename T>
+__device__ __forceinline__ void mma_chunk(f32x16& acc, const float4& a, const float4& b);
+template <>
+__device__ __forceinline__ void mma_chunk<float>(f32x16& acc, const float4& a, const float4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
 }
+template <>
+__device__ __forceinline__ void mma_chunk<bf16_t>(f32x16& acc, const float4& a, const float4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0,
+                                                  0, 0);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, ROWB = 128, CH = 8, RPI = 8, NW = 8, NSTAGE = 2;
+    constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr int A_INSTR = BM / RPI / NW, B_INSTR = BN / RPI / NW, IPS = A_INSTR + B_INSTR;
+    constexpr int KE = ROWB / (int)sizeof(T);   // k elements per stage
+    constexpr int EPC = 16 / (int)sizeof(T);    // elements per 16-byte chunk
+    constexpr int MB = 4, NB = 2, NG = CH / 2;  // blocks per wave, k-groups per stage
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = wg / g.tiles_n, tn = wg - tm * g.tiles_n;
+    const int KS = g.K / KE;
+
+    auto swz = [](int r) { return (r >> 1) & 7; };
+    const int dma_r = lane / CH, dma_p = lane % CH;
+    const u32 lds0 = (u32)(uintptr_t)(OTTER_AS3 char*)smem;
+    u32 voff[IPS];
+#pragma unroll
+    for (int t = 0; t < IPS; ++t) {
+        const int i = (t < A_INSTR ? t : t - A_INSTR) * NW + wave;
+        const int r = RPI * i + dma_r;
+        const u32 ld = t < A_INSTR ? (u32)g.lda : (u32)g.ldw;
+        voff[t] = ((u32)r * ld + (u32)((dma_p ^ swz(r)) * EPC)) * (u32)sizeof(T);
+    }
+    const T* gA0 = (const T*)g.A + (size_t)tm * BM * g.lda;
+    const T* gW0 = (const T*)g.W + (size_t)tn * BN * g.ldw;
+    auto produce = [&](int ks, int slot, int t) {
+        const u32 base = lds0 + slot * STAGE_BYTES;
+        if (t < A_INSTR) dma16s(gA0 + (size_t)ks * KE, voff[t], base + (t * NW + wave) * 1024);
+        else dma16s(gW0 + (size_t)ks * KE, voff[t], base + A_BYTES + ((t - A_INSTR) * NW + wave) * 1024);
+    };
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+#pragma unroll
+    for (int t = 0; t < IPS; ++t) produce(0, 0, t);
+
+    const int h = lane >> 5, l31 = lane & 31, lswz = swz(l31);
+    int slot = 0;
+    for (int ks = 0; ks < KS; ++ks) {
+        wait_vmcnt<0>();   // stage ks (issued one stage ago) has landed for this wave
+        wg_barrier();      // ... and for every wave; slot^1 is free again
+        const char* sA = smem + slot * STAGE_BYTES;
+        const char* sB = sA + A_BYTES;
+        float4 af[2][MB], bf[2][NB];
+        auto load_frags = [&](int j, int buf) {
+            const int coff = ((2 * j + h) ^ lswz) << 4;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+                af[buf][m] = *reinterpret_cast<const float4*>(sA + ((wm * MB + m) * 32 + l31) * ROWB + coff);
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+                bf[buf][n] = *reinterpret_cast<const float4*>(sB + ((wn * NB + n) * 32 + l31) * ROWB + coff);
+        };
+        load_frags(0, 0);
+        const bool more = ks + 1 < KS;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int cb = j & 1;
+            if (j + 1 < NG) load_frags(j + 1, cb ^ 1);
+            if (more) {
+#pragma unroll
+                for (int t = j; t < IPS; t += NG) produce(ks + 1, slot ^ 1, t);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) mma_chunk<T>(acc[m][n], af[cb][m], bf[cb][n]);
+        }
+        slot ^= 1;
+    }
+
+    // epilogue: lane owns column (l31) of each block, 16 rows per block
+    T* C = (T*)g.C;
+    const T* R = (const T*)g.R;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int col = tn * BN + (wn * NB + n) * 32 + l31;
+        const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = tm * BM + (wm * MB + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float v = acc[m][n][r] + bv;
+                if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+                if (EPI == EPI_BIAS_RESID) v += to_f<T>(R[(size_t)row * g.ldc + col]);
+                C[(size_t)row * g.ldc + col] = from_f<T>(v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ attention
+// One workgroup = 128 query rows of one (batch, head); 4 waves x 32 queries.  Scores are computed
+// transposed (S^T = K Q^T: keys on the accumulator rows, the query on the lane), so the softmax
+// statistics of a query are lane-local and the probability tile is already the B operand of the
+// second product O^T = V^T P^T ("accumulator tile as the next MFMA's operand").
+struct AttnArgs {
+    const void* QKV;    // [M_pad + 64, 3H]: q | k | v
+    void* CTX;          // [M_pad, H]
+    const float* kbias; // [B*L]: 0 for tokens, -1e30 for padding
+    int B, L, H, heads;
+    float scale;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+    constexpr int DH = 64, KB = 64;
+    constexpr int ROWB = DH * (int)sizeof(T);   // 128 (bf16) / 256 (fp32) bytes per K/V row
+    constexpr int CH = ROWB / 16;               // 16-byte chunks per row
+    constexpr int NQ = CH / 2;                  // fragment chunks per lane
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr bool BF = sizeof(T) == 2;
+    __shared__ __attribute__((aligned(16))) char sK[KB * ROWB];
+    __shared__ __attribute__((aligned(16))) char sV[KB * ROWB];
+    __shared__ float sBias[KB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int ld = 3 * a.H;
+    const T* base = (const T*)a.QKV + (size_t)b * a.L * ld + head * DH;
+    auto swz = [](int r) { return CH == 16 ? (r & 15) : ((r >> 1) & 7); };
+
+    // this lane's query row (clamped: rows past L are computed and dropped)
+    const int qrow = min(q0 + l31, a.L - 1);
+    float4 qf[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+        qf[j] = *reinterpret_cast<const float4*>(base + (size_t)qrow * ld + (2 * j + h) * EPC);
+
+    f32x16 o[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.0f;
+    float mrun = -INFINITY, lrun = 0.0f;
+
+    for (int kb0 = 0; kb0 < a.L; kb0 += KB) {
+        __syncthreads();
+        // stage K (swizzled chunks) and V (row-major) of keys kb0 .. kb0+63
+        for (int c = tid; c < KB * CH; c += 256) {
+            const int r = c / CH, p = c % CH;
+            const T* src = base + (size_t)(kb0 + r) * ld;
+            *reinterpret_cast<float4*>(sK + r * ROWB + ((p ^ swz(r)) << 4)) =
+                *reinterpret_cast<const float4*>(src + a.H + p * EPC);
+            *reinterpret_cast<float4*>(sV + r * ROWB + (p << 4)) =
+                *reinterpret_cast<const float4*>(src + 2 * a.H + p * EPC);
+        }
+        if (tid < KB) sBias[tid] = (kb0 + tid < a.L) ? a.kbias[(size_t)b * a.L + kb0 + tid] : -1e30f;
+        __syncthreads();
+
+        // S^T = K Q^T for the two 32-key halves
+        f32x16 s[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[sub][r] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const int krow = sub * 32 + l31;
+                const float4 kf =
+                    *reinterpret_cast<const float4*>(sK + krow * ROWB + (((2 * j + h) ^ swz(krow)) << 4));
+                mma_chunk<T>(s[sub], kf, qf[j]);
+            }
+        }
+        // scale, key-padding bias, running max
+        float mx = -INFINITY;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = s[sub][r] * a.scale + sBias[key];
+                s[sub][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mnew = fmaxf(mrun, mx);
+        const float alpha = __expf(mrun - mnew);
+        float psum = 0.0f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(s[sub][r] - mnew);
+                s[sub][r] = p;
+                psum += p;
+            }
+        psum += __shfl_xor(psum, 32);
+        lrun = lrun * alpha + psum;
+        mrun = mnew;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+
+        // O^T += V^T P^T
+        if constexpr (BF) {
+            const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3, dcol0 = 16 * ((lane >> 4) & 1);
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    // B fragment: registers 8*s2 .. 8*s2+7 of the probability tile, as bf16
+                    bf16x8 pb;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pb[j] = (__bf16)s[sub][8 * s2 + j];
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        // A fragment: V^T[d][key], key = 32 sub + 16 s2 + 8 (j>>2) + 4 h + (j&3),
+                        // two transposed LDS reads of 4 keys x 16 columns per 16-lane group
+                        const int kbase = sub * 32 + s2 * 16 + 4 * h;
+                        const char* p0 = sV + (kbase + qq) * ROWB + (d * 32 + dcol0 + 4 * pp) * 2;
+                        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((OTTER_AS3 s16x4*)p0);
+                        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((OTTER_AS3 s16x4*)(p0 + 8 * ROWB));
+                        short va[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                        bf16x8 av;
+                        __builtin_memcpy(&av, va, 16);
+                        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pb, o[d], 0, 0, 0);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int key = sub * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        const float av = *reinterpret_cast<const float*>(sV + key * ROWB + (d * 32 + l31) * 4);
+                        o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s[sub][t], o[d], 0, 0, 0);
+                    }
+                }
+        }
+    }
+
+    // normalise and store: lane = query, registers = head dimension
+    const int q = q0 + l31;
+    if (q < a.L) {
+        const float inv = 1.0f / lrun;
+        T* dst = (T*)a.CTX + ((size_t)b * a.L + q) * a.H + head * DH;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[d * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = from_f<T>(o[d][r] * inv);
+    }
+}
+
+// ------------------------------------------------------------------ row kernels
+// RoBERTa position ids: cumsum(ids != pad) * (ids != pad) + pad  (modeling_roberta.py:142-155);
+// BERT: arange(L).  Also writes the additive key-padding bias from input_mask.
+__global__ void prep_kernel(const long long* ids, const long long* mask, int* pos, float* kbias, int L, int pad,
+                            int roberta) {
+    const int b = blockIdx.x, lane = threadIdx.x;  // one wave per sequence
+    int run = 0;
+    for (int c0 = 0; c0 < L; c0 += 64) {
+        const int l = c0 + lane;
+        const bool in = l < L;
+        const bool tok = in && ids[(size_t)b * L + l] != pad;
+        const unsigned long long bal = __ballot(tok);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (in) {
+            pos[(size_t)b * L + l] = roberta ? (tok ? run + before + 1 + pad : pad) : l;
+            kbias[(size_t)b * L + l] = mask[(size_t)b * L + l] != 0 ? 0.0f : -1e30f;
+        }
+        run += __popcll(bal);
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// X[m] = LN(word[ids] + pos[pos_ids] + type[type_ids]); one wave per token, H = 256 * NV
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const long long* ids, const int* pos, const long long* types,
+                                                       const float* word, const float* pemb, const float* temb,
+                                                       const float* gamma, const float* beta, T* X, int M, int H,
+                                                       int vocab, int npos, int ntype, float eps) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= M) return;
+    long long id = ids[m];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    int p = pos[m];
+    p = p < 0 ? 0 : (p >= npos ? npos - 1 : p);
+    long long ty = types ? types[m] : 0;
+    ty = ty < 0 ? 0 : (ty >= ntype ? ntype - 1 : ty);
+    float v[NV * 4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        const float4 w = *reinterpret_cast<const float4*>(word + (size_t)id * H + c);
+        const float4 q = *reinterpret_cast<const float4*>(pemb + (size_t)p * H + c);
+        const float4 t = *reinterpret_cast<const float4*>(temb + (size_t)ty * H + c);
+        v[4 * i + 0] = w.x + q.x + t.x;
+        v[4 * i + 1] = w.y + q.y + t.y;
+        v[4 * i + 2] = w.z + q.z + t.z;
+        v[4 * i + 3] = w.w + q.w + t.w;
+        sum += v[4 * i] + v[4 * i + 1] + v[4 * i + 2] + v[4 * i + 3];
+    }
+    const float mean = wave_sum(sum) / H;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV * 4; ++i) var += (v[i] - mean) * (v[i] - mean);
+    const float rstd = rsqrtf(wave_sum(var) / H + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            X[(size_t)m * H + c + e] = from_f<T>((v[4 * i + e] - mean) * rstd * gamma[c + e] + beta[c + e]);
+    }
+}
+
+// Y[m] = LN(X[m]); one wave per row
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_kernel(const T* X, const float* gamma, const float* beta, T* Y, int M, int H,
+                                                 float eps) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= M) return;
+    float v[NV * 4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[4 * i + e] = to_f<T>(X[(size_t)m * H + c + e]);
+            sum += v[4 * i + e];
+        }
+    }
+    const float mean = wave_sum(sum) / H;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV * 4; ++i) var += (v[i] - mean) * (v[i] - mean);
+    const float rstd = rsqrtf(wave_sum(var) / H + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            Y[(size_t)m * H + c + e] = from_f<T>((v[4 * i + e] - mean) * rstd * gamma[c + e] + beta[c + e]);
+    }
+}
+
+// pooling_masked_part (tb_retriever.py:42-58) + concat: grid (B, parts); out fp32 [B, D]
+// part 0 = h[:,0] (skipped when the projection kernel writes it), parts 1,2 = pooled by mask.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_kernel(const T* X, const long long* mask2, const long long* mask3,
+                                                   float* out, int L, int H, int D, int method, int part_lo) {
+    const int b = blockIdx.x, part = blockIdx.y + part_lo, tid = threadIdx.x;
+    const T* hb = X + (size_t)b * L * H;
+    float* ob = out + (size_t)b * D + (size_t)part * H;
+    __shared__ int sIdx;
+    __shared__ float sCnt[4];
+    if (part == 0 || method == OTTER_POOL_CLS || method < 0 || method > OTTER_POOL_FIRST) {
+        for (int c = tid; c < H; c += 256) ob[c] = to_f<T>(hb[c]);
+        return;
+    }
+    const long long* mk = (part == 1 ? mask2 : mask3) + (size_t)b * L;
+    if (method == OTTER_POOL_FIRST) {
+        // argmax(mask * arange(L, 0, -1)): the first position holding the largest mask value;
+        // for a 0/1 mask the first 1, and row 0 when the mask is empty
+        if (tid == 0) {
+            long long best = 0;
+            int idx = 0;
+            for (int l = 0; l < L; ++l) {
+                const long long v = mk[l] * (long long)(L - l);
+                if (v > best) { best = v; idx = l; }
+            }
+            sIdx = idx;
+        }
+        __syncthreads();
+        const T* row = hb + (size_t)sIdx * H;
+        for (int c = tid; c < H; c += 256) ob[c] = to_f<T>(row[c]);
+        return;
+    }
+    for (int c = tid; c < H; c += 256) {
+        float acc = method == OTTER_POOL_MAX ? -INFINITY : 0.f;
+        float cnt = 0.f;
+        for (int l = 0; l < L; ++l) {
+            const float mv = (float)mk[l];
+            const float hv = to_f<T>(hb[(size_t)l * H + c]);
+            if (method == OTTER_POOL_MAX) acc = fmaxf(acc, hv + (1.0f - mv) * -1e5f);
+            else acc += hv * mv;
+            cnt += mv;
+        }
+        if (method == OTTER_POOL_MEAN) acc = acc / cnt;   // empty mask -> NaN, as the reference
+        ob[c] = acc;
+    }
+    (void)sCnt;
+}
+
+// part1 = LN(Linear(h[:,0]))  (project = Sequential(Linear, LayerNorm), tb_retriever.py:162-163)
+template <typename T>
+__global__ __launch_bounds__(256) void proj_ln_kernel(const T* X, const float* W, const float* bias,
+                                                      const float* gamma, const float* beta, float* out, int L, int H,
+                                                      int D, float eps) {
+    extern __shared__ float sh[];   // [H] input, [H] output, [8] reduce
+    float* xin = sh;
+    float* y = sh + H;
+    float* red = sh + 2 * H;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const T* row = X + (size_t)b * L * H;
+    for (int c = tid; c < H; c += 256) xin[c] = to_f<T>(row[c]);
+    __syncthreads();
+    float lsum = 0.f;
+    for (int n = tid; n < H; n += 256) {
+        const float* w = W + (size_t)n * H;
+        float acc = 0.f;
+        for (int k = 0; k < H; ++k) acc = fmaf(w[k], xin[k], acc);
+        acc += bias[n];
+        y[n] = acc;
+        lsum += acc;
+    }
+    lsum = wave_sum(lsum);
+    if ((tid & 63) == 0) red[tid >> 6] = lsum;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / H;
+    float lvar = 0.f;
+    for (int n = tid; n < H; n += 256) lvar += (y[n] - mean) * (y[n] - mean);
+    lvar = wave_sum(lvar);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = lvar;
+    __syncthreads();
+    const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / H + eps);
+    for (int n = tid; n < H; n += 256) out[(size_t)b * D + n] = (y[n] - mean) * rstd * gamma[n] + beta[n];
+}
+
+template <typename T>
+__global__ void to_f32_kernel(const T* src, float* dst, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = to_f<T>(src[i]);
+}
+
+template <typename T>
+__global__ void from_f32_kernel(const float* src, T* dst, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = from_f<T>(src[i]);
+}
+
+// ------------------------------------------------------------------ host side
+
+struct Tensor {
+    float* d = nullptr;
+    std::vector<int64_t> shape;
+    size_t numel() const {
+        size_t n = 1;
+        for (auto s : shape) n *= (size_t)s;
+        return n;
+    }
+};
+
+struct LayerW {
+    void* wqkv = nullptr;   // [3H, H] in T
+    float* bqkv = nullptr;  // [3H]
+    void *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
+    const float *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+    const float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+};
+
+}  // namespace
+
+struct otter_encoder {
+    otter_encoder_cfg cfg;
+    int device = 0;
+    int dtype = -1;   // compute type after finalize
+    std::map<std::string, Tensor> w;
+    std::vector<LayerW> layers;
+    std::vector<void*> owned;   // packed buffers
+    // workspace (grow-only)
+    otter::DevBuf X, X1, QKV, CTX, TMP, MID, pos, kbias;
+    long long ws_rows = 0;
+};
+
+namespace {
+
+size_t esize(int dtype) { return dtype == OTTER_BF16 ? 2 : 4; }
+
+int expected_shape(const otter_encoder_cfg& c, const std::string& name, std::vector<int64_t>* shp, bool* ignored) {
+    const int64_t H = c.hidden_size, I = c.intermediate_size;
+    *ignored = false;
+    auto ends = [&](const char* s) {
+        const size_t n = strlen(s);
+        return name.size() >= n && name.compare(name.size() - n, n, s) == 0;
+    };
+    if (ends("position_ids") || ends("token_type_ids")) { *ignored = true; return 0; }   // HF buffers
+    if (name.rfind("pooler.", 0) == 0) { *ignored = true; return 0; }                    // unused by the path ([0] only)
+    if (name == "embeddings.word_embeddings.weight") { *shp = {c.vocab_size, H}; return 0; }
+    if (name == "embeddings.position_embeddings.weight") { *shp = {c.max_position_embeddings, H}; return 0; }
+    if (name == "embeddings.token_type_embeddings.weight") { *shp = {c.type_vocab_size, H}; return 0; }
+    if (name == "embeddings.LayerNorm.weight" || name == "embeddings.LayerNorm.bias") { *shp = {H}; return 0; }
+    if (name == "project.0.weight") { *shp = {H, H}; return 0; }
+    if (name == "project.0.bias" || name == "project.1.weight" || name == "project.1.bias") { *shp = {H}; return 0; }
+    if (name.rfind("encoder.layer.", 0) == 0) {
+        const char* p = name.c_str() + 14;
+        char* end = nullptr;
+        const long li = strtol(p, &end, 10);
+        if (end == p || *end != '.' || li < 0 || li >= c.num_hidden_layers) return -1;
+        const std::string rest(end + 1);
+        if (rest == "attention.self.query.weight" || rest == "attention.self.key.weight" ||
+            rest == "attention.self.value.weight" || rest == "attention.output.dense.weight") { *shp = {H, H}; return 0; }
+        if (rest == "intermediate.dense.weight") { *shp = {I, H}; return 0; }
+        if (rest == "output.dense.weight") { *shp = {H, I}; return 0; }
+        if (rest == "intermediate.dense.bias") { *shp = {I}; return 0; }
+        if (rest == "attention.self.query.bias" || rest == "attention.self.key.bias" ||
+            rest == "attention.self.value.bias" || rest == "attention.output.dense.bias" ||
+            rest == "output.dense.bias" || rest == "attention.output.LayerNorm.weight" ||
+            rest == "attention.output.LayerNorm.bias" || rest == "output.LayerNorm.weight" ||
+            rest == "output.LayerNorm.bias") { *shp = {H}; return 0; }
+    }
+    return -1;
+}
+
+template <typename T>
+int convert_to(const float* src, void* dst, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(from_f32_kernel<T>, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, st, src,
+                       (T*)dst, (long long)n);
+    OTTER_HIP_TRY(hipGetLastError());
+    return OTTER_OK;
+}
+
+int dev_alloc(otter_encoder* e, void** p, size_t bytes) {
+    OTTER_HIP_TRY(hipMalloc(p, bytes));
+    e->owned.push_back(*p);
+    return OTTER_OK;
+}
+
+template <typename T>
+int finalize_t(otter_encoder* e) {
+    const auto& c = e->cfg;
+    const size_t H = c.hidden_size, I = c.intermediate_size;
+    hipStream_t st = nullptr;
+    e->layers.resize(c.num_hidden_layers);
+    for (int li = 0; li < c.num_hidden_layers; ++li) {
+        const std::string p = "encoder.layer." + std::to_string(li) + ".";
+        LayerW& L = e->layers[li];
+        int rc;
+        if ((rc = dev_alloc(e, &L.wqkv, 3 * H * H * sizeof(T)))) return rc;
+        if ((rc = dev_alloc(e, (void**)&L.bqkv, 3 * H * sizeof(float)))) return rc;
+        const char* names[3] = {"attention.self.query", "attention.self.key", "attention.self.value"};
+        for (int t = 0; t < 3; ++t) {
+            if ((rc = convert_to<T>(e->w[p + names[t] + ".weight"].d, (char*)L.wqkv + t * H * H * sizeof(T), H * H, st)))
+                return rc;
+            OTTER_HIP_TRY(hipMemcpyAsync(L.bqkv + t * H, e->w[p + names[t] + ".bias"].d, H * sizeof(float),
+                                         hipMemcpyDeviceToDevice, st));
+        }
+        struct { const char* n; void** dst; size_t cnt; } mats[3] = {
+            {"attention.output.dense.weight", &L.wo, H * H},
+            {"intermediate.dense.weight", &L.w1, I * H},
+            {"output.dense.weight", &L.w2, H * I}};
+        for (auto& m : mats) {
+            if (sizeof(T) == 4) {
+                *m.dst = e->w[p + m.n].d;   // fp32: use the uploaded tensor in place
+            } else {
+                if ((rc = dev_alloc(e, m.dst, m.cnt * sizeof(T)))) return rc;
+                if ((rc = convert_to<T>(e->w[p + m.n].d, *m.dst, m.cnt, st))) return rc;
+            }
+        }
+        L.bo = e->w[p + "attention.output.dense.bias"].d;
+        L.b1 = e->w[p + "intermediate.dense.bias"].d;
+        L.b2 = e->w[p + "output.dense.bias"].d;
+        L.ln1g = e->w[p + "attention.output.LayerNorm.weight"].d;
+        L.ln1b = e->w[p + "attention.output.LayerNorm.bias"].d;
+        L.ln2g = e->w[p + "output.LayerNorm.weight"].d;
+        L.ln2b = e->w[p + "output.LayerNorm.bias"].d;
+    }
+    OTTER_HIP_TRY(hipStreamSynchronize(st));
+    return OTTER_OK;
+}
+
+int ensure_ws(otter_encoder* e, long long M) {
+    const long long rows = round_up64(M, 256) + 64;
+    if (rows <= e->ws_rows) return OTTER_OK;
+    const size_t H = e->cfg.hidden_size, I = e->cfg.intermediate_size, es = esize(e->dtype);
+    int rc;
+    struct { otter::DevBuf* b; size_t bytes; } bufs[] = {
+        {&e->X, (size_t)rows * H * es},   {&e->X1, (size_t)rows * H * es},  {&e->QKV, (size_t)rows * 3 * H * es},
+        {&e->CTX, (size_t)rows * H * es}, {&e->TMP, (size_t)rows * H * es}, {&e->MID, (size_t)rows * I * es},
+        {&e->pos, (size_t)rows * 4},      {&e->kbias, (size_t)rows * 4}};
+    for (auto& b : bufs) {
+        if ((rc = b.b->reserve(b.bytes))) return rc;
+        // padding rows must stay finite (they are read as GEMM rows and as masked attention keys)
+        OTTER_HIP_TRY(hipMemset(b.b->p, 0, b.b->bytes));
+    }
+    e->ws_rows = rows;
+    return OTTER_OK;
+}
+
+template <typename T>
+int launch_gemm(int epi, const void* A, const void* W, const float* bias, const void* R, void* C, long long M, int N,
+                int K, hipStream_t st) {
+    GemmArgs g;
+    g.A = A; g.W = W; g.bias = bias; g.R = R; g.C = C;
+    g.tiles_m = (int)(round_up64(M, 256) / 256);
+    g.tiles_n = N / 256;
+    g.K = K; g.lda = K; g.ldw = K; g.ldc = N;
+    const size_t lds = 2 * 512 * 128;
+    void (*kern)(GemmArgs) = epi == EPI_BIAS ? gemm_kernel<T, EPI_BIAS>
+                             : epi == EPI_BIAS_GELU ? gemm_kernel<T, EPI_BIAS_GELU>
+                                                    : gemm_kernel<T, EPI_BIAS_RESID>;
+    OTTER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+    hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), lds, st, g);
+    OTTER_HIP_TRY(hipGetLastError());
+    return OTTER_OK;
+}
+
+template <typename T, int NV>
+int run_layers_nv(otter_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* types, int B, int L,
+                  int n_layers, hipStream_t st) {
+    const auto& c = e->cfg;
+    const long long M = (long long)B * L;
+    const int H = c.hidden_size, I = c.intermediate_size;
+    int rc;
+    hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(64), 0, st, (const long long*)ids, (const long long*)mask,
+                       (int*)e->pos.p, (float*)e->kbias.p, L, c.pad_token_id, c.position_mode == OTTER_POS_ROBERTA);
+    const unsigned rowgrid = (unsigned)((M + 3) / 4);
+    hipLaunchKernelGGL((embed_ln_kernel<T, NV>), dim3(rowgrid), dim3(256), 0, st, (const long long*)ids,
+                       (const int*)e->pos.p, (const long long*)types, e->w["embeddings.word_embeddings.weight"].d,
+                       e->w["embeddings.position_embeddings.weight"].d, e->w["embeddings.token_type_embeddings.weight"].d,
+                       e->w["embeddings.LayerNorm.weight"].d, e->w["embeddings.LayerNorm.bias"].d, (T*)e->X.p, (int)M, H,
+                       c.vocab_size, c.max_position_embeddings, c.type_vocab_size, c.layer_norm_eps);
+    OTTER_HIP_TRY(hipGetLastError());
+    for (int li = 0; li < n_layers; ++li) {
+        const LayerW& W = e->layers[li];
+        if ((rc = launch_gemm<T>(EPI_BIAS, e->X.p, W.wqkv, W.bqkv, nullptr, e->QKV.p, M, 3 * H, H, st))) return rc;
+        AttnArgs a;
+        a.QKV = e->QKV.p; a.CTX = e->CTX.p; a.kbias = (const float*)e->kbias.p;
+        a.B = B; a.L = L; a.H = H; a.heads = c.num_attention_heads;
+        a.scale = 1.0f / sqrtf((float)(H / c.num_attention_heads));
+        hipLaunchKernelGGL(attn_kernel<T>, dim3((L + 127) / 128, c.num_attention_heads, B), dim3(256), 0, st, a);
+        OTTER_HIP_TRY(hipGetLastError());
+        if ((rc = launch_gemm<T>(EPI_BIAS_RESID, e->CTX.p, W.wo, W.bo, e->X.p, e->TMP.p, M, H, H, st))) return rc;
+        hipLaunchKernelGGL((ln_kernel<T, NV>), dim3(rowgrid), dim3(256), 0, st, (const T*)e->TMP.p, W.ln1g, W.ln1b,
+                           (T*)e->X1.p, (int)M, H, c.layer_norm_eps);
+        if ((rc = launch_gemm<T>(EPI_BIAS_GELU, e->X1.p, W.w1, W.b1, nullptr, e->MID.p, M, I, H, st))) return rc;
+        if ((rc = launch_gemm<T>(EPI_BIAS_RESID, e->MID.p, W.w2, W.b2, e->X1.p, e->TMP.p, M, H, I, st))) return rc;
+        hipLaunchKernelGGL((ln_kernel<T, NV>), dim3(rowgrid), dim3(256), 0, st, (const T*)e->TMP.p, W.ln2g, W.ln2b,
+                           (T*)e->X.p, (int)M, H, c.layer_norm_eps);
+        OTTER_HIP_TRY(hipGetLastError());
+    }
+    return OTTER_OK;
+}
+
+template <typename T>
+int run_layers(otter_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* types, int B, int L,
+               int n_layers, hipStream_t st) {
+    switch (e->cfg.hidden_size / 256) {
+        case 1: return run_layers_nv<T, 1>(e, ids, mask, types, B, L, n_layers, st);
+        case 2: return run_layers_nv<T, 2>(e, ids, mask, types, B, L, n_layers, st);
+        case 3: return run_layers_nv<T, 3>(e, ids, mask, types, B, L, n_layers, st);
+        case 4: return run_layers_nv<T, 4>(e, ids, mask, types, B, L, n_layers, st);
+    }
+    return set_err(OTTER_ENOTIMPL, "hidden_size %d not supported", e->cfg.hidden_size);
+}
+
+template <typename T>
+int pool_out(otter_encoder* e, const int64_t* p2, const int64_t* p3, int B, int L, float* out, hipStream_t st) {
+    const auto& c = e->cfg;
+    const int H = c.hidden_size, D = c.three_cat ? 3 * H : H;
+    int part_lo = 0;
+    if (!c.no_proj) {
+        hipLaunchKernelGGL(proj_ln_kernel<T>, dim3(B), dim3(256), (2 * H + 8) * sizeof(float), st, (const T*)e->X.p,
+                           e->w["project.0.weight"].d, e->w["project.0.bias"].d, e->w["project.1.weight"].d,
+                           e->w["project.1.bias"].d, out, L, H, D, c.layer_norm_eps);
+        part_lo = 1;
+    }
+    const int parts = (c.three_cat ? 3 : 1) - part_lo;
+    if (parts > 0)
+        hipLaunchKernelGGL(pool_kernel<T>, dim3(B, parts), dim3(256), 0, st, (const T*)e->X.p, (const long long*)p2,
+                           (const long long*)p3, out, L, H, D, c.part_pooling, part_lo);
+    OTTER_HIP_TRY(hipGetLastError());
+    return OTTER_OK;
+}
+
+int check_call(otter_encoder* e, const void* ids, const void* mask, int B, int L, const char* what) {
+    if (!e) return set_err(OTTER_EINVAL, "%s: encoder is NULL", what);
+    if (e->dtype < 0) return set_err(OTTER_ESTATE, "%s: call otter_encoder_finalize first", what);
+    if (!ids || !mask) return set_err(OTTER_EINVAL, "%s: input_ids and input_mask must be non-NULL", what);
+    if (B < 1 || L < 1) return set_err(OTTER_EINVAL, "%s: bad batch shape B=%d L=%d", what, B, L);
+    const int maxL = e->cfg.position_mode == OTTER_POS_ROBERTA
+                         ? e->cfg.max_position_embeddings - e->cfg.pad_token_id - 1
+                         : e->cfg.max_position_embeddings;
+    if (L > maxL) return set_err(OTTER_EINVAL, "%s: L=%d exceeds the position table (max %d)", what, L, maxL);
+    if ((long long)B * L > (1ll << 30)) return set_err(OTTER_EINVAL, "%s: B*L too large", what);
+    return OTTER_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int otter_encoder_create(const otter_encoder_cfg* cfg, int device, otter_encoder** out) {
+    if (!out) return set_err(OTTER_EINVAL, "encoder_create: out is NULL");
+    *out = nullptr;
+    if (!cfg) return set_err(OTTER_EINVAL, "encoder_create: cfg is NULL");
+    const otter_encoder_cfg& c = *cfg;
+    if (c.hidden_size <= 0 || c.hidden_size % 256 != 0 || c.hidden_size > 1024)
+        return set_err(OTTER_ENOTIMPL, "encoder_create: hidden_size %d must be 256, 512, 768 or 1024", c.hidden_size);
+    if (c.num_attention_heads <= 0 || c.hidden_size != c.num_attention_heads * 64)
+        return set_err(OTTER_ENOTIMPL, "encoder_create: head dimension must be 64 (hidden %d, heads %d)", c.hidden_size,
+                       c.num_attention_heads);
+    if (c.intermediate_size <= 0 || c.intermediate_size % 256 != 0)
+        return set_err(OTTER_ENOTIMPL, "encoder_create: intermediate_size %d must be a multiple of 256",
+                       c.intermediate_size);
+    if (c.num_hidden_layers < 1 || c.vocab_size < 1 || c.max_position_embeddings < 1 || c.type_vocab_size < 1)
+        return set_err(OTTER_EINVAL, "encoder_create: bad layer/vocab/position/type sizes");
+    if (c.part_pooling < OTTER_POOL_MEAN || c.part_pooling > OTTER_POOL_FIRST)
+        return set_err(OTTER_EINVAL, "encoder_create: unknown pooling %d", c.part_pooling);
+    if (c.position_mode != OTTER_POS_BERT && c.position_mode != OTTER_POS_ROBERTA)
+        return set_err(OTTER_EINVAL, "encoder_create: unknown position_mode %d", c.position_mode);
+    int ndev = 0;
+    OTTER_HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+        return set_err(OTTER_EINVAL, "encoder_create: device %d out of range (%d visible)", device, ndev);
+    hipDeviceProp_t prop;
+    OTTER_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_err(OTTER_ESTATE, "encoder_create: device %d is %s; this library is built for gfx950 only", device,
+                       prop.gcnArchName);
+    otter_encoder* e = new (std::nothrow) otter_encoder();
+    if (!e) return set_err(OTTER_ENOMEM, "encoder_create: host allocation failed");
+    e->cfg = c;
+    e->device = device;
+    *out = e;
+    return OTTER_OK;
+}
+
+int otter_encoder_set_weight(otter_encoder* e, const char* name, const float* host_ptr, const int64_t* shape, int ndim) {
+    if (!e || !name || !host_ptr || !shape) return set_err(OTTER_EINVAL, "set_weight: NULL argument");
+    if (e->dtype >= 0) return set_err(OTTER_ESTATE, "set_weight: encoder already finalized");
+    std::vector<int64_t> want;
+    bool ignored = false;
+    if (expected_shape(e->cfg, name, &want, &ignored)) return set_err(OTTER_EINVAL, "set_weight: unknown tensor '%s'", name);
+    if (ignored) return OTTER_OK;
+    bool ok = (int)want.size() == ndim;
+    for (int i = 0; ok && i < ndim; ++i) ok = want[i] == shape[i];
+    if (!ok) {
+        std::string got, exp;
+        for (int i = 0; i < ndim; ++i) got += std::to_string(shape[i]) + (i + 1 < ndim ? "," : "");
+        for (size_t i = 0; i < want.size(); ++i) exp += std::to_string(want[i]) + (i + 1 < want.size() ? "," : "");
+        return set_err(OTTER_EINVAL, "set_weight: '%s' has shape [%s], expected [%s]", name, got.c_str(), exp.c_str());
+    }
+    DeviceGuard g(e->device);
+    if (!g.ok) return set_err(OTTER_EHIP, "set_weight: hipSetDevice(%d) failed", e->device);
+    Tensor& t = e->w[name];
+    t.shape = want;
+    const size_t bytes = t.numel() * sizeof(float);
+    if (!t.d) OTTER_HIP_TRY(hipMalloc((void**)&t.d, bytes));
+    OTTER_HIP_TRY(hipMemcpy(t.d, host_ptr, bytes, hipMemcpyHostToDevice));
+    return OTTER_OK;
+}
+
+int otter_encoder_finalize(otter_encoder* e, int compute_dtype) {
+    if (!e) return set_err(OTTER_EINVAL, "finalize: encoder is NULL");
+    if (e->dtype >= 0) return set_err(OTTER_ESTATE, "finalize: already finalized");
+    if (compute_dtype != OTTER_F32 && compute_dtype != OTTER_BF16)
+        return set_err(OTTER_ENOTIMPL, "finalize: compute dtype %d not built (OTTER_F32 or OTTER_BF16)", compute_dtype);
+    // every tensor the configured path reads must be present
+    std::vector<std::string> need = {"embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight",
+                                     "embeddings.token_type_embeddings.weight", "embeddings.LayerNorm.weight",
+                                     "embeddings.LayerNorm.bias"};
+    const char* per_layer[] = {"attention.self.query.weight", "attention.self.query.bias", "attention.self.key.weight",
+                               "attention.self.key.bias", "attention.self.value.weight", "attention.self.value.bias",
+                               "attention.output.dense.weight", "attention.output.dense.bias",
+                               "attention.output.LayerNorm.weight", "attention.output.LayerNorm.bias",
+                               "intermediate.dense.weight", "intermediate.dense.bias", "output.dense.weight",
+                               "output.dense.bias", "output.LayerNorm.weight", "output.LayerNorm.bias"};
+    for (int li = 0; li < e->cfg.num_hidden_layers; ++li)
+        for (const char* n : per_layer) need.push_back("encoder.layer." + std::to_string(li) + "." + n);
+    if (!e->cfg.no_proj)
+        for (const char* n : {"project.0.weight", "project.0.bias", "project.1.weight", "project.1.bias"}) need.push_back(n);
+    for (const auto& n : need)
+        if (e->w.find(n) == e->w.end()) return set_err(OTTER_ESTATE, "finalize: tensor '%s' was never set", n.c_str());
+    DeviceGuard g(e->device);
+    if (!g.ok) return set_err(OTTER_EHIP, "finalize: hipSetDevice(%d) failed", e->device);
+    int rc = compute_dtype == OTTER_BF16 ? finalize_t<bf16_t>(e) : finalize_t<float>(e);
+    if (rc) return rc;
+    e->dtype = compute_dtype;
+    return OTTER_OK;
+}
+
+int otter_encoder_forward(otter_encoder* e, const int64_t* input_ids, const int64_t* input_mask, const int64_t* type_ids,
+                          const int64_t* part2_mask, const int64_t* part3_mask, int B, int L, float* out, void* stream) {
+    int rc = check_call(e, input_ids, input_mask, B, L, "forward");
+    if (rc) return rc;
+    if (!out) return set_err(OTTER_EINVAL, "forward: out is NULL");
+    if (e->cfg.three_cat && e->cfg.part_pooling != OTTER_POOL_CLS && (!part2_mask || !part3_mask))
+        return set_err(OTTER_EINVAL, "forward: part2_mask and part3_mask are required for the three-vector encoder");
+    DeviceGuard g(e->device);
+    if (!g.ok) return set_err(OTTER_EHIP, "forward: hipSetDevice(%d) failed", e->device);
+    if ((rc = ensure_ws(e, (long long)B * L))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int nl = e->cfg.num_hidden_layers;
+    if (e->dtype == OTTER_BF16) {
+        if ((rc = run_layers<bf16_t>(e, input_ids, input_mask, type_ids, B, L, nl, st))) return rc;
+        return pool_out<bf16_t>(e, part2_mask, part3_mask, B, L, out, st);
+    }
+    if ((rc = run_layers<float>(e, input_ids, input_mask, type_ids, B, L, nl, st))) return rc;
+    return pool_out<float>(e, part2_mask, part3_mask, B, L, out, st);
+}
+
+int otter_encoder_forward_hidden(otter_encoder* e, const int64_t* input_ids, const int64_t* input_mask,
+                                 const int64_t* type_ids, int B, int L, int n_layers, float* hidden, void* stream) {
+    int rc = check_call(e, input_ids, input_mask, B, L, "forward_hidden");
+    if (rc) return rc;
+    if (!hidden) return set_err(OTTER_EINVAL, "forward_hidden: hidden is NULL");
+    if (n_layers < 0 || n_layers > e->cfg.num_hidden_layers)
+        return set_err(OTTER_EINVAL, "forward_hidden: n_layers=%d outside [0, %d]", n_layers, e->cfg.num_hidden_layers);
+    DeviceGuard g(e->device);
+    if (!g.ok) return set_err(OTTER_EHIP, "forward_hidden: hipSetDevice(%d) failed", e->device);
+    if ((rc = ensure_ws(e, (long long)B * L))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)B * L * e->cfg.hidden_size;
+    const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 8192);
+    if (e->dtype == OTTER_BF16) {
+        if ((rc = run_layers<bf16_t>(e, input_ids, input_mask, type_ids, B, L, n_layers, st))) return rc;
+        hipLaunchKernelGGL(to_f32_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)e->X.p, hidden, n);
+    } else {
+        if ((rc = run_layers<float>(e, input_ids, input_mask, type_ids, B, L, n_layers, st))) return rc;
+        hipLaunchKernelGGL(to_f32_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)e->X.p, hidden, n);
+    }
+    OTTER_HIP_TRY(hipGetLastError());
+    return OTTER_OK;
+}
+
+int otter_encoder_out_dim(const otter_encoder* e) {
+    if (!e) return -1;
+    return e->cfg.three_cat ? 3 * e->cfg.hidden_size : e->cfg.hidden_size;
+}
+
+void otter_encoder_destroy(otter_encoder* e) {
+    if (!e) return;
+    DeviceGuard g(e->device);
+    for (auto& kv : e->w)
+        if (kv.second.d) (void)hipFree(kv.second.d);
+    for (void* p : e->owned) (void)hipFree(p);
+    e->X.release(); e->X1.release(); e->QKV.release(); e->CTX.release();
+    e->TMP.release(); e->MID.release(); e->pos.release(); e->kbias.release();
+    delete e;
+}
+
+}  // extern "C"
