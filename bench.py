@@ -117,15 +117,15 @@ def main():
     q = gen_rows(nq, d, 4321, dev)
 
     if world > 1:
-        Dg = torch.empty((world, nq, k), dtype=torch.float32, device=dev)
-        Ig = torch.empty((world, nq, k), dtype=torch.int64, device=dev)
+        Dg = torch.empty((world * nq, k), dtype=torch.float32, device=dev)
+        Ig = torch.empty((world * nq, k), dtype=torch.int64, device=dev)
 
     def step():
         D, I = index.search(q, k)
         if world > 1:
             dist.all_gather_into_tensor(Dg, D)
             dist.all_gather_into_tensor(Ig, I)
-            D, I = merge_topk(Dg, Ig, device=local_rank)
+            D, I = merge_topk(Dg.view(world, nq, k), Ig.view(world, nq, k), device=local_rank)
         return D, I
 
     for _ in range(args.warmup):
