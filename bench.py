@@ -61,7 +61,7 @@ def cpu_baseline(xb_sample_fn, q, k, rows_full, budget_s=15.0):
     flat_ip.search_batched(xb, q, k)
     dt = time.perf_counter() - t0
     rows2 = int(min(rows_full, max(rows, rows * budget_s / max(dt, 1e-3))))
-    rows2 = min(rows2, 400000)
+    rows2 = min(rows2, 1000000)
     if rows2 > rows * 2:
         xb = xb_sample_fn(rows2)
         t0 = time.perf_counter()
@@ -74,6 +74,88 @@ def cpu_baseline(xb_sample_fn, q, k, rows_full, budget_s=15.0):
                       "%.1f s, scaled by rows" % (nq, rows, rows_full, dt)}
 
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: Peak BF16 MFMA, dense
+
+
+def encode_leg(rank, world, local_rank, dist, steps, warmup, batch, cpu_ref):
+    """Second half of the metric: corpus-encode blocks/s (BASELINE.json configs[3] shape: roberta-base,
+    512-token blocks, bf16, data-parallel = every rank encodes its own blocks with resident weights,
+    no data-path collective).  Synthetic ids per SURVEY.md §8d, random weights (seed 99)."""
+    from types import SimpleNamespace
+    from oracle import encoder_ref as R     # shape + seeded weight generator; CPU baseline below
+    from otter_amd import encoder as E
+    L, H, layers = 512, 768, 12
+    cfg = R.make_config("roberta")
+    sd = R.make_state_dict(cfg, 99)
+    hf = SimpleNamespace(**{k: cfg[k] for k in ("vocab_size", "hidden_size", "num_hidden_layers",
+                                                "num_attention_heads", "intermediate_size",
+                                                "max_position_embeddings", "type_vocab_size", "pad_token_id",
+                                                "layer_norm_eps")})
+    a = SimpleNamespace(shared_encoder=True, no_proj=True, part_pooling="first", encode_table=True)
+    model = E.RobertaSingleEncoderThreeCatPool(hf, a, dtype="bf16")
+    model.load_state_dict(sd, strict=False)
+    model.to("cuda:%d" % local_rank)
+    rs = np.random.RandomState(777 + rank)
+    ids = rs.randint(3, cfg["vocab_size"], size=(batch, L)).astype(np.int64)
+    ids[:, 0] = 0
+    ids[:, 128] = 2
+    ids[:, 129] = 2
+    ids[:, L - 1] = 2
+    p2 = np.zeros((batch, L), np.int64)
+    p2[:, 1:128] = 1
+    p3 = np.zeros((batch, L), np.int64)
+    p3[:, 130:L - 1] = 1
+    b = {"input_ids": torch.from_numpy(ids).cuda(), "input_mask": torch.ones((batch, L), dtype=torch.int64).cuda(),
+         "part2_mask": torch.from_numpy(p2).cuda(), "part3_mask": torch.from_numpy(p3).cuda()}
+    for _ in range(warmup):
+        out = model(b)["embed"]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        out = model(b)["embed"]
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=out.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return None
+    dev_ms = e0.elapsed_time(e1) / steps
+    flops_block = layers * (24.0 * L * H * H + 4.0 * L * L * H)
+    achieved = flops_block * batch / (dev_ms * 1e-3) / 1e12
+    res = {"value": world * batch * steps / elapsed, "unit": "blocks/s", "dtype": "bf16", "batch_per_gpu": batch,
+           "seq_len": L, "model": "roberta-base shape, random init", "ms_per_batch": elapsed / steps * 1e3,
+           "finite": bool(torch.isfinite(out).all().item()),
+           "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
+                        "kernel": "whole forward (12 x [qkv gemm, attention, o gemm, ln, ffn1 gemm, ffn2 gemm, ln])",
+                        "device_ms_per_batch": dev_ms, "algorithmic_flops_per_block": flops_block}}
+    if cpu_ref:
+        # fp32 recall-style check of the bf16 path on 2 blocks + CPU baseline timing (oracle restatement)
+        ref = R.EncoderRef(cfg, sd)
+        nb = 4
+        small = {k: v[:nb].cpu() for k, v in b.items()}
+        ref(small)                                   # warm-up (thread pool, allocations)
+        t0 = time.perf_counter()
+        exp = ref(small)["embed"]
+        dt = time.perf_counter() - t0
+        got = out[:nb].cpu()
+        cos = torch.nn.functional.cosine_similarity(got.view(nb * 3, H), exp.view(nb * 3, H), dim=1)
+        res["bf16_vs_fp32_oracle_min_cosine"] = float(cos.min())
+        res["cpu_baseline"] = {"value": nb / dt, "unit": "blocks/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "%d blocks of 512 tokens, oracle/encoder_ref.py (torch CPU fp32), %.1f s"
+                                         % (nb, dt)}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +166,8 @@ def main():
     ap.add_argument("--nq", type=int, default=2214)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-encode", action="store_true", help="skip the corpus-encode leg")
+    ap.add_argument("--encode-batch", type=int, default=128)
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per scan launch from a separate rocprofv3 --pmc pass (profiles/)")
     args = ap.parse_args()
@@ -110,11 +194,12 @@ def main():
     xb = gen_rows(n, d, 1234 + rank, dev)
     index = IndexFlatIP(d, device=local_rank, id_base=rank * n)
     index.add(xb)
-    xb_head = xb[: min(n, 400000)].cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    xb_head = xb.cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     check_rows = xb[:65536].clone()
     del xb
     torch.cuda.empty_cache()
     q = gen_rows(nq, d, 4321, dev)
+    qh = q.cpu().numpy()
 
     if world > 1:
         Dg = torch.empty((world * nq, k), dtype=torch.float32, device=dev)
@@ -161,6 +246,14 @@ def main():
         ok = bool((got >= rs[:, -1:] - 1e-3).all().item()) and bool(((Ds.double() - got).abs() < 1e-2).all().item())
         small.close()
 
+    index.close()
+    del index, q, check_rows
+    torch.cuda.empty_cache()
+    enc = None
+    if not args.no_encode:
+        enc = encode_leg(rank, world, local_rank, dist, max(2, args.steps // 4), 1, args.encode_batch,
+                         world == 1 and not args.no_cpu_baseline)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * nq * args.steps / elapsed
@@ -187,7 +280,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": args.traffic_bytes,
-                         "kernel": "scan_kernel<2,2,2,2,2,6> (fp32 v_mfma_f32_32x32x2_f32 + fused top-k filter)",
+                         "kernel": "scan_kernel<4,2,2,2,32,3,8> (256x128 tile, fp32 v_mfma_f32_32x32x2_f32 + fused top-k filter)",
                          "kernel_ms": kern_ms, "launches": int(launches),
                          "algorithmic_flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": float(n) * d * 4 + nq * d * 4 + nq * k * 12,
@@ -195,8 +288,9 @@ def main():
                          if kern_ms > 0 else 0.0},
             "self_check": "ok" if ok else "FAILED",
         }
+        if enc is not None:
+            out["encode"] = enc
         if world == 1 and not args.no_cpu_baseline:
-            qh = q.cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(lambda r: xb_head[:r], qh, k, n)
         print(json.dumps(out), flush=True)
         if not ok:

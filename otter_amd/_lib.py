@@ -74,6 +74,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise OtterError("libotter_hip.so not found at %s: build it with `python -m otter_amd.build` "
                          "(there is no CPU fallback)" % LIB_PATH)
+    # Load order matters: PyTorch-ROCm ships its own HIP runtime.  If this library pulled in the
+    # system runtime first, a later `import torch` would bring a second runtime into the process
+    # and one of the two then sees no device.  Importing torch first makes both share one runtime.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # numpy-only callers: the system runtime is the only one
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
