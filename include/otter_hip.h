@@ -178,6 +178,16 @@ int otter_encoder_forward_hidden(otter_encoder* enc,
                                  const int64_t* type_ids, int B, int L, int n_layers,
                                  float* hidden, void* stream);
 
+/* Parity hook (no counterpart call in the reference): the bf16 GEMM every projection of the
+ * encoder runs on, exposed so that tests can compare it with a plain fp32 matmul.
+ * C[M, N] = A[M, K] * W[N, K]^T + bias[N]   (epi 0)
+ *                                 ... then GELU(erf)          (epi 1)
+ *                                 ... + R[M, N]               (epi 2)
+ * A, W, R, C: device bf16 row-major; bias: device float32 or NULL.
+ * M and N multiples of 256, K a multiple of 64. */
+int otter_gemm_bf16(int device, int epi, const void* A, const void* W, const float* bias, const void* R,
+                    void* C, int64_t M, int N, int K, void* stream);
+
 int  otter_encoder_out_dim(const otter_encoder* enc);
 void otter_encoder_destroy(otter_encoder* enc);
 

@@ -55,6 +55,7 @@ SIGNATURES = {
     "otter_encoder_finalize": (c_int, [c_vp, c_int]),
     "otter_encoder_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "otter_encoder_forward_hidden": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    "otter_gemm_bf16": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "otter_encoder_out_dim": (c_int, [c_vp]),
     "otter_encoder_destroy": (None, [c_vp]),
 }

@@ -13,8 +13,8 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, "csrc")
 LIB = os.path.join(_PKG, "libotter_hip.so")
 OBJDIR = os.path.join(_PKG, "csrc", "_obj")
-SOURCES = ["common.hip", "index.hip", "encoder.hip"]
-HEADERS = ["otter_common.h", os.path.join("..", "..", "include", "otter_hip.h")]
+SOURCES = ["common.hip", "index.hip", "encoder.hip", "gemm_bf16.hip"]
+HEADERS = ["otter_common.h", "otter_device.h", "otter_gemm.h", os.path.join("..", "..", "include", "otter_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

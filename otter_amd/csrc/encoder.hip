@@ -24,6 +24,7 @@
 
 #include "otter_common.h"
 #include "otter_device.h"
+#include "otter_gemm.h"
 
 namespace {
 
@@ -547,6 +548,7 @@ struct LayerW {
 struct otter_encoder {
     otter_encoder_cfg cfg;
     int device = 0;
+    int ncu = 256;
     int dtype = -1;   // compute type after finalize
     std::map<std::string, Tensor> w;
     std::vector<LayerW> layers;
@@ -672,7 +674,9 @@ int ensure_ws(otter_encoder* e, long long M) {
 
 template <typename T>
 int launch_gemm(int epi, const void* A, const void* W, const float* bias, const void* R, void* C, long long M, int N,
-                int K, hipStream_t st) {
+                int K, int ncu, hipStream_t st) {
+    if (sizeof(T) == 2 && K % 64 == 0)   // bf16 throughput path: persistent ping-pong kernel (gemm_bf16.hip)
+        return launch_gemm_bf16(epi, A, W, bias, R, C, round_up64(M, 256), N, K, ncu, st);
     GemmArgs g;
     g.A = A; g.W = W; g.bias = bias; g.R = R; g.C = C;
     g.tiles_m = (int)(round_up64(M, 256) / 256);
@@ -707,18 +711,18 @@ int run_layers_nv(otter_encoder* e, const int64_t* ids, const int64_t* mask, con
     OTTER_HIP_TRY(hipGetLastError());
     for (int li = 0; li < n_layers; ++li) {
         const LayerW& W = e->layers[li];
-        if ((rc = launch_gemm<T>(EPI_BIAS, e->X.p, W.wqkv, W.bqkv, nullptr, e->QKV.p, M, 3 * H, H, st))) return rc;
+        if ((rc = launch_gemm<T>(EPI_BIAS, e->X.p, W.wqkv, W.bqkv, nullptr, e->QKV.p, M, 3 * H, H, e->ncu, st))) return rc;
         AttnArgs a;
         a.QKV = e->QKV.p; a.CTX = e->CTX.p; a.kbias = (const float*)e->kbias.p;
         a.B = B; a.L = L; a.H = H; a.heads = c.num_attention_heads;
         a.scale = 1.0f / sqrtf((float)(H / c.num_attention_heads));
         hipLaunchKernelGGL(attn_kernel<T>, dim3((L + 127) / 128, c.num_attention_heads, B), dim3(256), 0, st, a);
         OTTER_HIP_TRY(hipGetLastError());
-        if ((rc = launch_gemm<T>(EPI_BIAS_RESID, e->CTX.p, W.wo, W.bo, e->X.p, e->TMP.p, M, H, H, st))) return rc;
+        if ((rc = launch_gemm<T>(EPI_BIAS_RESID, e->CTX.p, W.wo, W.bo, e->X.p, e->TMP.p, M, H, H, e->ncu, st))) return rc;
         hipLaunchKernelGGL((ln_kernel<T, NV>), dim3(rowgrid), dim3(256), 0, st, (const T*)e->TMP.p, W.ln1g, W.ln1b,
                            (T*)e->X1.p, (int)M, H, c.layer_norm_eps);
-        if ((rc = launch_gemm<T>(EPI_BIAS_GELU, e->X1.p, W.w1, W.b1, nullptr, e->MID.p, M, I, H, st))) return rc;
-        if ((rc = launch_gemm<T>(EPI_BIAS_RESID, e->MID.p, W.w2, W.b2, e->X1.p, e->TMP.p, M, H, I, st))) return rc;
+        if ((rc = launch_gemm<T>(EPI_BIAS_GELU, e->X1.p, W.w1, W.b1, nullptr, e->MID.p, M, I, H, e->ncu, st))) return rc;
+        if ((rc = launch_gemm<T>(EPI_BIAS_RESID, e->MID.p, W.w2, W.b2, e->X1.p, e->TMP.p, M, H, I, e->ncu, st))) return rc;
         hipLaunchKernelGGL((ln_kernel<T, NV>), dim3(rowgrid), dim3(256), 0, st, (const T*)e->TMP.p, W.ln2g, W.ln2b,
                            (T*)e->X.p, (int)M, H, c.layer_norm_eps);
         OTTER_HIP_TRY(hipGetLastError());
@@ -806,6 +810,7 @@ int otter_encoder_create(const otter_encoder_cfg* cfg, int device, otter_encoder
     if (!e) return set_err(OTTER_ENOMEM, "encoder_create: host allocation failed");
     e->cfg = c;
     e->device = device;
+    e->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     *out = e;
     return OTTER_OK;
 }
@@ -906,6 +911,17 @@ int otter_encoder_forward_hidden(otter_encoder* e, const int64_t* input_ids, con
     }
     OTTER_HIP_TRY(hipGetLastError());
     return OTTER_OK;
+}
+
+int otter_gemm_bf16(int device, int epi, const void* A, const void* W, const float* bias, const void* R, void* C,
+                    int64_t M, int N, int K, void* stream) {
+    if (!A || !W || !C) return set_err(OTTER_EINVAL, "gemm_bf16: NULL operand");
+    if (epi < GEMM_EPI_BIAS || epi > GEMM_EPI_BIAS_RESID) return set_err(OTTER_EINVAL, "gemm_bf16: unknown epilogue %d", epi);
+    DeviceGuard g(device);
+    if (!g.ok) return set_err(OTTER_EHIP, "gemm_bf16: hipSetDevice(%d) failed", device);
+    hipDeviceProp_t prop;
+    OTTER_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    return launch_gemm_bf16(epi, A, W, bias, R, C, M, N, K, prop.multiProcessorCount, (hipStream_t)stream);
 }
 
 int otter_encoder_out_dim(const otter_encoder* e) {

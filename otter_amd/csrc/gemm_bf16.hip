@@ -1,0 +1,369 @@
+// gemm_bf16.hip — the encoder's bf16 GEMM on gfx950: C = A W^T + bias (+ GELU | + residual).
+//
+// Serves the four projections of a BERT/RoBERTa layer that the reference reaches through HF's
+// AutoModel (retrieval/models/tb_retriever.py:180-185): QKV, attention output, FFN up, FFN down.
+//
+// Structure (persistent, one 512-thread workgroup per CU, 256 x 256 output tiles, K-step 64):
+//   * 8 waves = 2 groups x 4.  Group g owns token rows [128g, 128g+128) of the tile, wave wn of a
+//     group owns feature columns [64wn, 64wn+64): a 128 x 64 wave tile held as 8 x 4 accumulators
+//     of v_mfma_f32_16x16x32_bf16 (features on the accumulator rows, tokens on the lanes, so the
+//     epilogue can store 16 B of consecutive features per lane).
+//   * The two groups run the same program one barrier apart ("ping-pong"): while one group's
+//     waves issue 16 MFMAs (one 64 x 32 quadrant over the whole K-step) the other group's waves,
+//     which share the same four SIMDs, read fragments from LDS and issue LDS-DMA.
+//   * LDS holds two K-steps, each as four 16 KiB half-tiles in the order they are consumed:
+//     A-first (token rows of quadrant row 0 of both groups), B-first (feature rows of quadrant
+//     column 0 of all four waves), B-second, A-second.  One half-tile is DMA'd per phase
+//     (global_load_lds_dwordx4, 2 per wave), six half-tiles ahead of the consumer, across output
+//     tiles (the stream of K-steps is flat over this workgroup's tiles), and retired with a
+//     counted s_waitcnt vmcnt(8): four half-tiles stay in flight, the loop never drains to zero.
+//   * 128-byte LDS rows, 16-B chunks XOR-swizzled through the DMA *source* address
+//     (chunk ^ ((row >> 1) & 7)): every ds_read_b128 lane group hits 16 distinct slots.
+//   * Epilogue: bias is the accumulators' initial value; v_permlane16_swap pairs two feature
+//     blocks so that a lane holds 8 consecutive features of one token -> one 16-B store
+//     (and one 16-B residual load).  The two groups' epilogues run in the same barrier interval.
+//
+// Hazard bookkeeping (segments are the intervals between barriers; group 1 is one behind):
+//   RAW  a half-tile retired by the wait in segment j is read no earlier than segment j + 2;
+//   WAR  a slot is refilled no earlier than 3 segments after its last ds_read was issued.
+// With half-tile h = 4u + p + 6 issued in load phase p of K-step u both hold by construction
+// (table in DESIGN.md §4).
+#include <algorithm>
+
+#include "otter_device.h"
+#include "otter_gemm.h"
+
+namespace {
+
+using namespace otter;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct PPArgs {
+    const char* A;      // [M_pad][lda] bf16
+    const char* W;      // [N][ldw] bf16
+    const float* bias;  // [N] or null
+    const bf16_t* R;    // [M_pad][ldc] bf16 (EPI_BIAS_RESID)
+    bf16_t* C;          // [M_pad][ldc] bf16
+    int tiles_m, tiles_n, KT, N;
+    int lda, ldw, ldc;  // elements
+};
+
+constexpr int HT = 16384;            // one half-tile: 128 rows x 128 B
+constexpr int BUF = 4 * HT;          // one K-step
+constexpr int OFF_AF = 0, OFF_BF = HT, OFF_BS = 2 * HT, OFF_AS = 3 * HT;
+
+__device__ __forceinline__ void bar() { asm volatile("s_barrier" ::: "memory"); }
+
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16 resolution):
+// gelu(x) = 0.5 x (1 + erf(x / sqrt 2))
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
+    const float h = x * (0.5f * p * t * e);     // 0.5 x (1 - erf(z))
+    return x > 0.0f ? x - h : h;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sbias = reinterpret_cast<float*>(smem + 2 * BUF);   // [N] bias (zeros without one)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int bid = blockIdx.x, nblk = gridDim.x;
+    const int KT = a.KT;
+
+    // ---- tile schedule.  Workgroups b, b + 8, ... share an XCD and its L2: give every XCD a
+    // contiguous range of tile rows and walk it in patches of 8 tile rows x all tile columns
+    // (column-major inside a patch), so that the workgroups of an XCD, which take consecutive
+    // list positions, work on ~8 A tiles x ~4 W tiles at a time instead of 32 x 1.
+    // Any schedule is correct; this one is for L2 hits only.
+    const bool xmode = (nblk & 7) == 0;
+    const int wpx = xmode ? nblk >> 3 : nblk;                  // list stride of this workgroup
+    const int idx = xmode ? bid >> 3 : bid;                    // first list position
+    int tm0 = 0, n_tm = a.tiles_m;
+    if (xmode) {
+        const int x = bid & 7;
+        tm0 = (int)(((long long)x * a.tiles_m) >> 3);
+        n_tm = (int)(((long long)(x + 1) * a.tiles_m) >> 3) - tm0;
+    }
+    const int list_len = n_tm * a.tiles_n;
+    const int n_my = idx < list_len ? (list_len - idx + wpx - 1) / wpx : 0;
+    const int total_stages = n_my * KT;
+    if (total_stages == 0) return;   // whole workgroup
+    const int full_blocks = n_tm >> 3, per_block = 8 * a.tiles_n;
+    auto coords = [&](int j, int& tm, int& tn) {
+        const int pos = idx + wpx * j;
+        const int blk = pos / per_block;
+        if (blk < full_blocks) {
+            const int rem = pos - blk * per_block;
+            tn = rem >> 3;
+            tm = tm0 + 8 * blk + (rem & 7);
+        } else {
+            const int bsz = n_tm - 8 * full_blocks;
+            const int rem = pos - full_blocks * per_block;
+            tn = rem / bsz;
+            tm = tm0 + 8 * full_blocks + (rem - tn * bsz);
+        }
+    };
+
+    for (int i = tid; i < a.N; i += 512) sbias[i] = a.bias ? a.bias[i] : 0.0f;
+
+    // ---- producer: per-lane source offsets (bytes), fixed for the kernel
+    u32 voffA[2], voffB[2];
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) {
+        const int r = 8 * (wave * 2 + i2) + (lane >> 3);       // LDS row of the half-tile
+        const int c = (lane & 7) ^ ((r >> 1) & 7);             // source chunk landing at position lane & 7
+        const int arow = (r & 63) + 128 * (r >> 6);            // A-first: quadrant row 0 of group r >> 6
+        const int wrow = 64 * (r >> 5) + (r & 31);             // B-first: quadrant column 0 of wave r >> 5
+        voffA[i2] = ((u32)arow * (u32)a.lda + (u32)c * 8u) * 2u;
+        voffB[i2] = ((u32)wrow * (u32)a.ldw + (u32)c * 8u) * 2u;
+    }
+    const u32 lds0 = (u32)(uintptr_t)(OTTER_AS3 char*)smem;
+    const u32 dma_dst = (u32)(wave * 2) * 1024u;
+
+    int is_stage = 0, is_t = 0, is_j = 0;
+    bool is_valid = false;
+    const char* is_tileA = a.A;
+    const char* is_tileW = a.W;
+    const char* is_gA = a.A;
+    const char* is_gW = a.W;
+    u32 is_lds = lds0;
+    auto is_set_tile = [&]() {
+        int tm, tn;
+        coords(is_j, tm, tn);
+        is_tileA = a.A + (size_t)tm * 256 * a.lda * 2;
+        is_tileW = a.W + (size_t)tn * 256 * a.ldw * 2;
+    };
+    is_set_tile();
+    // kind: 0 A-first, 1 B-first, 2 B-second, 3 A-second (compile-time at every call site)
+    auto issue = [&](int kind) -> bool {
+        if (kind == 0) {
+            is_valid = is_stage < total_stages;
+            if (is_valid) {
+                is_gA = is_tileA + (size_t)is_t * 128;
+                is_gW = is_tileW + (size_t)is_t * 128;
+                is_lds = lds0 + (u32)(is_stage & 1) * BUF + dma_dst;
+                ++is_stage;
+                if (++is_t == KT) {
+                    is_t = 0;
+                    if (++is_j < n_my) is_set_tile();
+                }
+            }
+        }
+        if (is_valid) {
+            if (kind == 0) {
+                dma16s(is_gA, voffA[0], is_lds + OFF_AF);
+                dma16s(is_gA, voffA[1], is_lds + OFF_AF + 1024);
+            } else if (kind == 1) {
+                dma16s(is_gW, voffB[0], is_lds + OFF_BF);
+                dma16s(is_gW, voffB[1], is_lds + OFF_BF + 1024);
+            } else if (kind == 2) {
+                const char* b = is_gW + (size_t)32 * a.ldw * 2;
+                dma16s(b, voffB[0], is_lds + OFF_BS);
+                dma16s(b, voffB[1], is_lds + OFF_BS + 1024);
+            } else {
+                const char* b = is_gA + (size_t)64 * a.lda * 2;
+                dma16s(b, voffA[0], is_lds + OFF_AS);
+                dma16s(b, voffA[1], is_lds + OFF_AS + 1024);
+            }
+        }
+        return is_valid;
+    };
+
+    // ---- consumer state
+    f32x4 acc[8][4];
+    int c_j = 0, c_t = 0, c_tm = 0, c_tn = 0;
+    coords(0, c_tm, c_tn);
+    auto init_acc = [&]() {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(sbias + c_tn * 256 + wn * 64 + nb * 16 + 4 * fq);
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb) acc[mb][nb] = b;
+        }
+    };
+    const u32 xrow = (u32)(64 * g + fr) * 128u;
+    const u32 wrow = (u32)(32 * wn + fr) * 128u;
+    const u32 coff0 = (u32)((fq) ^ (fr >> 1)) << 4;
+    const u32 coff1 = (u32)((4 + fq) ^ (fr >> 1)) << 4;
+    // fragments: X0 / X1 = token rows of quadrant row 0 / 1, Wf[nq] = feature rows of quadrant column nq
+    float4 X0[4][2], X1[4][2], Wf[2][2][2];
+    auto ldX = [&](float4 (&X)[4][2], const char* base) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            X[mb][0] = *reinterpret_cast<const float4*>(base + xrow + mb * 2048 + coff0);
+            X[mb][1] = *reinterpret_cast<const float4*>(base + xrow + mb * 2048 + coff1);
+        }
+    };
+    auto ldW = [&](int nq, const char* base) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            Wf[nq][nb][0] = *reinterpret_cast<const float4*>(base + wrow + nb * 2048 + coff0);
+            Wf[nq][nb][1] = *reinterpret_cast<const float4*>(base + wrow + nb * 2048 + coff1);
+        }
+    };
+    auto mma = [&](float4 (&X)[4][2], int mq, int nq) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[4 * mq + mb][2 * nq + nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, Wf[nq][nb][ks]), __builtin_bit_cast(bf16x8, X[mb][ks]),
+                        acc[4 * mq + mb][2 * nq + nb], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // `after_store`: the tile epilogue's 16 stores per lane sit inside the window of the four
+    // youngest half-tiles for the next three phases; allow them to stay outstanding too
+    auto stage_and_wait = [&](int kind, bool after_store) {
+        if (issue(kind)) {
+            if (after_store) wait_vmcnt<24>();
+            else wait_vmcnt<8>();
+        } else {
+            wait_vmcnt<0>();
+        }
+    };
+    auto epilogue = [&]() {
+        const int col0 = c_tn * 256 + wn * 64 + 8 * (fq >> 1) + 16 * (fq & 1);
+        const size_t row0 = (size_t)c_tm * 256 + g * 128 + fr;
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) {
+            const size_t rowoff = (row0 + mb * 16) * (size_t)a.ldc;
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u32x2 s = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mb][2 * jn][i]),
+                                                                     __float_as_uint(acc[mb][2 * jn + 1][i]), false,
+                                                                     false);
+                    v[i] = __uint_as_float(s[0]);
+                    v[4 + i] = __uint_as_float(s[1]);
+                }
+                const size_t off = rowoff + col0 + jn * 32;
+                if (EPI == GEMM_EPI_BIAS_RESID) {
+                    const uint4 rr = *reinterpret_cast<const uint4*>(a.R + off);
+                    const u32 w[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] += __uint_as_float(w[e] << 16);
+                        v[2 * e + 1] += __uint_as_float(w[e] & 0xFFFF0000u);
+                    }
+                }
+                if (EPI == GEMM_EPI_BIAS_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+                *reinterpret_cast<float4*>(a.C + off) = __builtin_bit_cast(float4, o);
+            }
+        }
+    };
+
+    // ---- prologue: half-tiles 0..5
+    issue(0); issue(1); issue(2); issue(3);
+    issue(0);
+    if (issue(1)) wait_vmcnt<8>();   // A-first(0), B-first(0) have landed
+    else wait_vmcnt<0>();
+    __syncthreads();                 // ... for every wave; the bias vector is in LDS
+    init_acc();
+    ldX(X0, smem + OFF_AF);
+    if (g == 1) bar();               // group 1 runs one barrier behind
+
+    for (int cs = 0; cs < total_stages; ++cs) {
+        const char* lb = smem + (cs & 1) * BUF;
+        const bool as = c_t == 0 && cs > 0;   // first K-step after an epilogue
+        // phase 0: quadrant (0, 0)
+        ldW(0, lb + OFF_BF);
+        stage_and_wait(2, as);
+        bar();
+        mma(X0, 0, 0);
+        bar();
+        // phase 1: quadrant (0, 1)
+        ldW(1, lb + OFF_BS);
+        stage_and_wait(3, as);
+        bar();
+        mma(X0, 0, 1);
+        bar();
+        // phase 2: quadrant (1, 1)
+        ldX(X1, lb + OFF_AS);
+        stage_and_wait(0, as);
+        bar();
+        mma(X1, 1, 1);
+        bar();
+        // phase 3: quadrant (1, 0); token fragments of the next K-step's quadrant row 0
+        if (cs + 1 < total_stages) ldX(X0, smem + ((cs + 1) & 1) * BUF + OFF_AF);
+        stage_and_wait(1, false);
+        bar();
+        mma(X1, 1, 0);
+        if (++c_t == KT) {
+            // both groups write their tile in the same barrier interval
+            c_t = 0;
+            if (g == 1) epilogue();
+            bar();
+            if (g == 0) epilogue();
+            if (++c_j < n_my) {
+                coords(c_j, c_tm, c_tn);
+                init_acc();
+            }
+        } else {
+            bar();
+        }
+    }
+    if (g == 0) bar();               // pairs with group 1's last barrier
+}
+
+}  // namespace
+
+namespace otter {
+
+int launch_gemm_bf16(int epi, const void* A, const void* W, const float* bias, const void* R, void* C,
+                     long long M_pad, int N, int K, int ncu, hipStream_t st) {
+    if (M_pad <= 0 || M_pad % 256 || N <= 0 || N % 256 || K <= 0 || K % 64)
+        return set_err(OTTER_EINVAL, "gemm_bf16: M_pad=%lld N=%d K=%d must be multiples of 256/256/64", M_pad, N, K);
+    if (epi == GEMM_EPI_BIAS_RESID && !R) return set_err(OTTER_EINVAL, "gemm_bf16: residual epilogue without R");
+    if ((long long)255 * std::max(N, K) * 2 + 128 > 0x7FFFFFFFll || M_pad / 256 * (N / 256) > 0x7FFFFFFFll)
+        return set_err(OTTER_EINVAL, "gemm_bf16: shape too large");
+    PPArgs a;
+    a.A = (const char*)A;
+    a.W = (const char*)W;
+    a.bias = bias;
+    a.R = (const bf16_t*)R;
+    a.C = (bf16_t*)C;
+    a.tiles_m = (int)(M_pad / 256);
+    a.tiles_n = N / 256;
+    a.KT = K / 64;
+    a.N = N;
+    a.lda = K;
+    a.ldw = K;
+    a.ldc = N;
+    void (*kern)(PPArgs) = epi == GEMM_EPI_BIAS ? gemm_pp_kernel<GEMM_EPI_BIAS>
+                           : epi == GEMM_EPI_BIAS_GELU ? gemm_pp_kernel<GEMM_EPI_BIAS_GELU>
+                                                       : gemm_pp_kernel<GEMM_EPI_BIAS_RESID>;
+    const int lds = 2 * BUF + N * (int)sizeof(float);
+    if (lds > 160 * 1024) return set_err(OTTER_EINVAL, "gemm_bf16: N=%d too wide for the LDS bias vector", N);
+    const int ntiles = a.tiles_m * a.tiles_n;
+    OTTER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int grid = std::min(ntiles, std::max(1, ncu));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+    OTTER_HIP_TRY(hipGetLastError());
+    return OTTER_OK;
+}
+
+}  // namespace otter
