@@ -178,8 +178,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
 struct AttnArgs {
     const void* QKV;    // [M_pad + 64, 3H]: q | k | v
     void* CTX;          // [M_pad, H]
-    const float* kbias; // [B*L]: 0 for tokens, -1e30 for padding
-    int B, L, H, heads;
+    const float* kbias; // [B][Lp]: 0 for tokens, -1e30 for padding and for keys in [L, Lp)
+    int B, L, Lp, H, heads;
     float scale;
 };
 
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             *reinterpret_cast<float4*>(sV + r * ROWB + (p << 4)) =
                 *reinterpret_cast<const float4*>(src + 2 * a.H + p * EPC);
         }
-        if (tid < KB) sBias[tid] = (kb0 + tid < a.L) ? a.kbias[(size_t)b * a.L + kb0 + tid] : -1e30f;
+        if (tid < KB) sBias[tid] = a.kbias[(size_t)b * a.Lp + kb0 + tid];
         __syncthreads();
 
         // S^T = K Q^T for the two 32-key halves
@@ -328,23 +328,276 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ attention, bf16 throughput path
+// One 512-thread workgroup per (batch, head); L <= 512.  All of K and V of the head are brought
+// into LDS once by LDS-DMA (64-key tiles, 2 pieces per wave per tile, issued back to back) and
+// released tile by tile with a counted s_waitcnt vmcnt + one barrier each; after the fill there is
+// no further synchronisation: every wave owns 64 queries (two 32-query blocks sharing each K / V
+// fragment read) and walks all keys with an online softmax in base 2
+// (p = exp2(s * scale * log2 e + bias - max)).  Layout of the products as in attn_kernel: scores
+// transposed (keys on accumulator rows, the query on the lane), the probability tile is the next
+// MFMA's B operand, V read transposed with ds_read_b64_tr_b16.  The context row is stored 16 B
+// per lane after a v_permlane32_swap of the two lane halves.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void dma4s(const void* sbase, u32 voff, u32 lds_dst) {   // 64 lanes x 4 B
+    u32 keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+
+__device__ __forceinline__ void wait_vmcnt_upto7(int n) {   // n in {0..7} or an even number <= 14
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<1>(); break;
+        case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;
+        case 5: wait_vmcnt<5>(); break;
+        case 6: wait_vmcnt<6>(); break;
+        case 7: wait_vmcnt<7>(); break;
+        case 8: wait_vmcnt<8>(); break;
+        case 10: wait_vmcnt<10>(); break;
+        case 12: wait_vmcnt<12>(); break;
+        default: wait_vmcnt<14>(); break;
+    }
+}
+
+template <int QB>
+__global__ __launch_bounds__(1024 / QB, QB == 2 ? 2 : 4) void attn_full_kernel(AttnArgs a) {
+    constexpr int NW = 16 / QB;      // waves; each moves PPW of the 16 1-KiB pieces of a 64-key tile
+    constexpr int PPW = 16 / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nt = a.Lp >> 6;                       // 64-key tiles
+    char* sK = smem;                                // [Lp][128 B], chunks swizzled by (row >> 1) & 7
+    char* sV = smem + nt * 8192;                    // [Lp][128 B], linear
+    float* sB = reinterpret_cast<float*>(smem + 2 * nt * 8192);   // [Lp] additive key bias
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const int ld = 3 * a.H;
+    const bf16_t* base = (const bf16_t*)a.QKV + (size_t)b * a.L * ld + head * 64;
+    const int q0 = wave * 32 * QB;
+    const bool active = q0 < a.L;                   // wave-uniform
+
+    // this lane's two query rows: loads hidden from hipcc (it would drain the DMA queue for them)
+    f32x4v qf[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qrow = min(q0 + qb * 32 + l31, a.L - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16_t* p = base + (size_t)qrow * ld + (2 * j + h) * 8;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf[qb][j]) : "v"(p) : "memory");
+        }
+    }
+    // fill: key bias, then K and V tile by tile (wave w moves rows 8w .. 8w+7 of every tile)
+    const u32 lds0 = (u32)(uintptr_t)(OTTER_AS3 char*)smem;
+    if (wave < nt) dma4s(a.kbias + (size_t)b * a.Lp + wave * 64, (u32)lane * 4u, lds0 + 2 * nt * 8192 + wave * 256);
+    {
+        // piece p of a tile: p < 8 -> K rows 8p .. 8p+7 (swizzled), else V rows 8(p-8) .. (linear)
+        u32 voff[PPW], dst[PPW];
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave * PPW + i, isv = p >> 3, r = 8 * (p & 7) + (lane >> 3);
+            const int c = isv ? (lane & 7) : ((lane & 7) ^ ((r >> 1) & 7));
+            voff[i] = ((u32)r * (u32)ld + (u32)(isv ? 2 * a.H : a.H) + (u32)(c * 8)) * 2u;
+            dst[i] = lds0 + (u32)(isv ? nt * 8192 : 0) + (u32)(p & 7) * 1024u;
+        }
+        for (int t = 0; t < nt; ++t) {
+            const char* tb = reinterpret_cast<const char*>(base) + (size_t)t * 64 * ld * 2;
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) dma16s(tb, voff[i], dst[i] + t * 8192);
+        }
+    }
+
+    f32x16 o[QB][2];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][d][r] = 0.0f;
+    float mrun[QB], lrun[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) { mrun[qb] = -INFINITY; lrun[qb] = 0.0f; }
+    const float scale2 = a.scale * 1.4426950408889634f;
+    const int lswz = (l31 >> 1) & 7;
+    const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3, dcol0 = 16 * ((lane >> 4) & 1);
+
+    for (int t = 0; t < nt; ++t) {
+        // tile t (and everything older: Q, bias) has landed for this wave, then for all waves
+        wait_vmcnt_upto7(PPW * (nt - 1 - t));
+        if (t == 0) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+                asm volatile("" : "+v"(qf[qb][0]), "+v"(qf[qb][1]), "+v"(qf[qb][2]), "+v"(qf[qb][3]));
+        }
+        asm volatile("s_barrier" ::: "memory");
+        if (!active) continue;
+        const char* kt = sK + t * 8192;
+        const char* vt = sV + t * 8192;
+
+        // S^T = K Q^T: [qb][sub] = 32 keys x 32 queries
+        f32x16 s[QB][2];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[qb][sub][r] = 0.0f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 kf =
+                    *reinterpret_cast<const float4*>(kt + (sub * 32 + l31) * 128 + (((2 * j + h) ^ lswz) << 4));
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+                    s[qb][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[qb][j]), s[qb][sub], 0, 0, 0);
+            }
+        // additive bias of this lane's 32 keys (shared by both query blocks)
+        float4 bv[2][4];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+                bv[sub][rq] = *reinterpret_cast<const float4*>(sB + t * 64 + sub * 32 + 8 * rq + 4 * h);
+
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float4 bb = bv[sub][r >> 2];
+                    const float bias = (r & 3) == 0 ? bb.x : (r & 3) == 1 ? bb.y : (r & 3) == 2 ? bb.z : bb.w;
+                    const float v = fmaf(s[qb][sub][r], scale2, bias);
+                    s[qb][sub][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            {
+                const u32x2v sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            const float mnew = fmaxf(mrun[qb], mx);
+            const float alpha = __builtin_amdgcn_exp2f(mrun[qb] - mnew);
+            float psum = 0.0f;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(s[qb][sub][r] - mnew);
+                    s[qb][sub][r] = pv;
+                    psum += pv;
+                }
+            {
+                const u32x2v sw =
+                    __builtin_amdgcn_permlane32_swap(__float_as_uint(psum), __float_as_uint(psum), false, false);
+                psum = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            }
+            lrun[qb] = lrun[qb] * alpha + psum;
+            mrun[qb] = mnew;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[qb][d][r] *= alpha;
+        }
+
+        // O^T += V^T P^T
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pb[QB];
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pb[qb][j] = (__bf16)s[qb][sub][8 * s2 + j];
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const int kbase = sub * 32 + s2 * 16 + 4 * h;
+                    const char* p0 = vt + (kbase + qq) * 128 + (d * 32 + dcol0 + 4 * pp) * 2;
+                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((OTTER_AS3 s16x4*)p0);
+                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((OTTER_AS3 s16x4*)(p0 + 8 * 128));
+                    short va[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    bf16x8 av;
+                    __builtin_memcpy(&av, va, 16);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb)
+                        o[qb][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pb[qb], o[qb][d], 0, 0, 0);
+                }
+            }
+    }
+
+    // normalise and store: lanes l and l + 32 hold one query; after the swap a lane holds 8
+    // consecutive head dimensions (16 B): half 0 -> [8 rq, 8 rq + 8), half 1 -> the next 8
+    if (active) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const int q = q0 + qb * 32 + l31;
+            const float inv = 1.0f / lrun[qb];
+            bf16_t* dst = (bf16_t*)a.CTX + ((size_t)b * a.L + min(q, a.L - 1)) * a.H + head * 64;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int rq = 0; rq < 4; rq += 2) {
+                    bf16x8 ov;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u32x2v sw = __builtin_amdgcn_permlane32_swap(
+                            __float_as_uint(o[qb][d][4 * rq + i] * inv), __float_as_uint(o[qb][d][4 * rq + 4 + i] * inv),
+                            false, false);
+                        ov[i] = (__bf16)__uint_as_float(sw[0]);
+                        ov[4 + i] = (__bf16)__uint_as_float(sw[1]);
+                    }
+                    if (q < a.L)
+                        *reinterpret_cast<float4*>(dst + d * 32 + 8 * (rq + h)) = __builtin_bit_cast(float4, ov);
+                }
+        }
+    }
+}
+
+int launch_attn_bf16(const AttnArgs& a, hipStream_t st) {
+    const int nt = a.Lp >> 6;
+    const int lds = 2 * nt * 8192 + nt * 256;
+    static const char* v = getenv("OTTER_ATTN_QB");   // A/B switch for tuning runs
+    if (v && v[0] == '2') {
+        OTTER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(attn_full_kernel<2>, dim3(a.heads, a.B), dim3(512), lds, st, a);
+    } else {
+        OTTER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(attn_full_kernel<1>, dim3(a.heads, a.B), dim3(1024), lds, st, a);
+    }
+    OTTER_HIP_TRY(hipGetLastError());
+    return OTTER_OK;
+}
+
 // ------------------------------------------------------------------ row kernels
 // RoBERTa position ids: cumsum(ids != pad) * (ids != pad) + pad  (modeling_roberta.py:142-155);
 // BERT: arange(L).  Also writes the additive key-padding bias from input_mask.
-__global__ void prep_kernel(const long long* ids, const long long* mask, int* pos, float* kbias, int L, int pad,
+// kbias is [B][Lp], Lp = L rounded up to 64: keys past L are masked like padding tokens.
+__global__ void prep_kernel(const long long* ids, const long long* mask, int* pos, float* kbias, int L, int Lp, int pad,
                             int roberta) {
     const int b = blockIdx.x, lane = threadIdx.x;  // one wave per sequence
     int run = 0;
-    for (int c0 = 0; c0 < L; c0 += 64) {
+    for (int c0 = 0; c0 < Lp; c0 += 64) {
         const int l = c0 + lane;
         const bool in = l < L;
         const bool tok = in && ids[(size_t)b * L + l] != pad;
         const unsigned long long bal = __ballot(tok);
         const int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (in) {
-            pos[(size_t)b * L + l] = roberta ? (tok ? run + before + 1 + pad : pad) : l;
-            kbias[(size_t)b * L + l] = mask[(size_t)b * L + l] != 0 ? 0.0f : -1e30f;
-        }
+        if (in) pos[(size_t)b * L + l] = roberta ? (tok ? run + before + 1 + pad : pad) : l;
+        kbias[(size_t)b * Lp + l] = (in && mask[(size_t)b * L + l] != 0) ? 0.0f : -1e30f;
         run += __popcll(bal);
     }
 }
@@ -654,15 +907,18 @@ int finalize_t(otter_encoder* e) {
     return OTTER_OK;
 }
 
-int ensure_ws(otter_encoder* e, long long M) {
+int ensure_ws(otter_encoder* e, int B, int L) {
+    const long long M = (long long)B * L;
     const long long rows = round_up64(M, 256) + 64;
+    int rc0 = e->kbias.reserve((size_t)B * round_up(L, 64) * sizeof(float));   // [B][Lp], fully written by prep_kernel
+    if (rc0) return rc0;
     if (rows <= e->ws_rows) return OTTER_OK;
     const size_t H = e->cfg.hidden_size, I = e->cfg.intermediate_size, es = esize(e->dtype);
     int rc;
     struct { otter::DevBuf* b; size_t bytes; } bufs[] = {
         {&e->X, (size_t)rows * H * es},   {&e->X1, (size_t)rows * H * es},  {&e->QKV, (size_t)rows * 3 * H * es},
         {&e->CTX, (size_t)rows * H * es}, {&e->TMP, (size_t)rows * H * es}, {&e->MID, (size_t)rows * I * es},
-        {&e->pos, (size_t)rows * 4},      {&e->kbias, (size_t)rows * 4}};
+        {&e->pos, (size_t)rows * 4}};
     for (auto& b : bufs) {
         if ((rc = b.b->reserve(b.bytes))) return rc;
         // padding rows must stay finite (they are read as GEMM rows and as masked attention keys)
@@ -699,9 +955,10 @@ int run_layers_nv(otter_encoder* e, const int64_t* ids, const int64_t* mask, con
     const auto& c = e->cfg;
     const long long M = (long long)B * L;
     const int H = c.hidden_size, I = c.intermediate_size;
+    const int Lp = round_up(L, 64);
     int rc;
     hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(64), 0, st, (const long long*)ids, (const long long*)mask,
-                       (int*)e->pos.p, (float*)e->kbias.p, L, c.pad_token_id, c.position_mode == OTTER_POS_ROBERTA);
+                       (int*)e->pos.p, (float*)e->kbias.p, L, Lp, c.pad_token_id, c.position_mode == OTTER_POS_ROBERTA);
     const unsigned rowgrid = (unsigned)((M + 3) / 4);
     hipLaunchKernelGGL((embed_ln_kernel<T, NV>), dim3(rowgrid), dim3(256), 0, st, (const long long*)ids,
                        (const int*)e->pos.p, (const long long*)types, e->w["embeddings.word_embeddings.weight"].d,
@@ -714,10 +971,14 @@ int run_layers_nv(otter_encoder* e, const int64_t* ids, const int64_t* mask, con
         if ((rc = launch_gemm<T>(EPI_BIAS, e->X.p, W.wqkv, W.bqkv, nullptr, e->QKV.p, M, 3 * H, H, e->ncu, st))) return rc;
         AttnArgs a;
         a.QKV = e->QKV.p; a.CTX = e->CTX.p; a.kbias = (const float*)e->kbias.p;
-        a.B = B; a.L = L; a.H = H; a.heads = c.num_attention_heads;
+        a.B = B; a.L = L; a.Lp = Lp; a.H = H; a.heads = c.num_attention_heads;
         a.scale = 1.0f / sqrtf((float)(H / c.num_attention_heads));
-        hipLaunchKernelGGL(attn_kernel<T>, dim3((L + 127) / 128, c.num_attention_heads, B), dim3(256), 0, st, a);
-        OTTER_HIP_TRY(hipGetLastError());
+        if (sizeof(T) == 2 && L <= 512) {
+            if ((rc = launch_attn_bf16(a, st))) return rc;
+        } else {
+            hipLaunchKernelGGL(attn_kernel<T>, dim3((L + 127) / 128, c.num_attention_heads, B), dim3(256), 0, st, a);
+            OTTER_HIP_TRY(hipGetLastError());
+        }
         if ((rc = launch_gemm<T>(EPI_BIAS_RESID, e->CTX.p, W.wo, W.bo, e->X.p, e->TMP.p, M, H, H, e->ncu, st))) return rc;
         hipLaunchKernelGGL((ln_kernel<T, NV>), dim3(rowgrid), dim3(256), 0, st, (const T*)e->TMP.p, W.ln1g, W.ln1b,
                            (T*)e->X1.p, (int)M, H, c.layer_norm_eps);
@@ -878,7 +1139,7 @@ int otter_encoder_forward(otter_encoder* e, const int64_t* input_ids, const int6
         return set_err(OTTER_EINVAL, "forward: part2_mask and part3_mask are required for the three-vector encoder");
     DeviceGuard g(e->device);
     if (!g.ok) return set_err(OTTER_EHIP, "forward: hipSetDevice(%d) failed", e->device);
-    if ((rc = ensure_ws(e, (long long)B * L))) return rc;
+    if ((rc = ensure_ws(e, B, L))) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int nl = e->cfg.num_hidden_layers;
     if (e->dtype == OTTER_BF16) {
@@ -898,7 +1159,7 @@ int otter_encoder_forward_hidden(otter_encoder* e, const int64_t* input_ids, con
         return set_err(OTTER_EINVAL, "forward_hidden: n_layers=%d outside [0, %d]", n_layers, e->cfg.num_hidden_layers);
     DeviceGuard g(e->device);
     if (!g.ok) return set_err(OTTER_EHIP, "forward_hidden: hipSetDevice(%d) failed", e->device);
-    if ((rc = ensure_ws(e, (long long)B * L))) return rc;
+    if ((rc = ensure_ws(e, B, L))) return rc;
     hipStream_t st = (hipStream_t)stream;
     const long long n = (long long)B * L * e->cfg.hidden_size;
     const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 8192);

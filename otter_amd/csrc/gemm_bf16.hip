@@ -29,6 +29,7 @@
 // With half-tile h = 4u + p + 6 issued in load phase p of K-step u both hold by construction
 // (table in DESIGN.md §4).
 #include <algorithm>
+#include <vector>
 
 #include "otter_device.h"
 #include "otter_gemm.h"
@@ -48,7 +49,21 @@ struct PPArgs {
     bf16_t* C;          // [M_pad][ldc] bf16
     int tiles_m, tiles_n, KT, N;
     int lda, ldw, ldc;  // elements
+    unsigned long long* dbg;   // GEMM_DIAG builds only
 };
+
+#ifdef GEMM_DIAG
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define DG(...) __VA_ARGS__
+#else
+#define DG(...)
+#endif
 
 constexpr int HT = 16384;            // one half-tile: 128 rows x 128 B
 constexpr int BUF = 4 * HT;          // one K-step
@@ -229,52 +244,81 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
     };
     // `after_store`: the tile epilogue's 16 stores per lane sit inside the window of the four
     // youngest half-tiles for the next three phases; allow them to stay outstanding too
+    DG(unsigned long long dW = 0, dI = 0;)
     auto stage_and_wait = [&](int kind, bool after_store) {
-        if (issue(kind)) {
+        DG(unsigned long long tw0 = stamp();)
+#if defined(GEMM_ABL) && GEMM_ABL == 1
+        const bool issued = true;
+#else
+        const bool issued = issue(kind);
+#endif
+        DG(unsigned long long tw1 = stamp(); dI += tw1 - tw0;)
+#if !defined(GEMM_ABL) || GEMM_ABL != 2
+        if (issued) {
             if (after_store) wait_vmcnt<24>();
             else wait_vmcnt<8>();
         } else {
             wait_vmcnt<0>();
         }
+#endif
+        DG(dW += stamp() - tw1;)
     };
     auto epilogue = [&]() {
         const int col0 = c_tn * 256 + wn * 64 + 8 * (fq >> 1) + 16 * (fq & 1);
         const size_t row0 = (size_t)c_tm * 256 + g * 128 + fr;
+        // two halves of 4 token blocks: the residual's 8 loads of a half are all issued before
+        // the first is consumed (one memory latency per half instead of one per 16-B unit)
 #pragma unroll
-        for (int mb = 0; mb < 8; ++mb) {
-            const size_t rowoff = (row0 + mb * 16) * (size_t)a.ldc;
+        for (int half = 0; half < 2; ++half) {
+            uint4 rr[4][2];
+            if (EPI == GEMM_EPI_BIAS_RESID) {
 #pragma unroll
-            for (int jn = 0; jn < 2; ++jn) {
-                float v[8];
+                for (int m4 = 0; m4 < 4; ++m4)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const u32x2 s = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mb][2 * jn][i]),
-                                                                     __float_as_uint(acc[mb][2 * jn + 1][i]), false,
-                                                                     false);
-                    v[i] = __uint_as_float(s[0]);
-                    v[4 + i] = __uint_as_float(s[1]);
-                }
-                const size_t off = rowoff + col0 + jn * 32;
-                if (EPI == GEMM_EPI_BIAS_RESID) {
-                    const uint4 rr = *reinterpret_cast<const uint4*>(a.R + off);
-                    const u32 w[4] = {rr.x, rr.y, rr.z, rr.w};
+                    for (int jn = 0; jn < 2; ++jn)
+                        rr[m4][jn] = *reinterpret_cast<const uint4*>(
+                            a.R + (row0 + (half * 4 + m4) * 16) * (size_t)a.ldc + col0 + jn * 32);
+            }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[2 * e] += __uint_as_float(w[e] << 16);
-                        v[2 * e + 1] += __uint_as_float(w[e] & 0xFFFF0000u);
+            for (int m4 = 0; m4 < 4; ++m4) {
+                const int mb = half * 4 + m4;
+                const size_t rowoff = (row0 + mb * 16) * (size_t)a.ldc;
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u32x2 s = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mb][2 * jn][i]),
+                                                                         __float_as_uint(acc[mb][2 * jn + 1][i]),
+                                                                         false, false);
+                        v[i] = __uint_as_float(s[0]);
+                        v[4 + i] = __uint_as_float(s[1]);
                     }
-                }
-                if (EPI == GEMM_EPI_BIAS_GELU) {
+                    if (EPI == GEMM_EPI_BIAS_RESID) {
+                        const u32 w[4] = {rr[m4][jn].x, rr[m4][jn].y, rr[m4][jn].z, rr[m4][jn].w};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
-                }
-                bf16x8 o;
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] += __uint_as_float(w[e] << 16);
+                            v[2 * e + 1] += __uint_as_float(w[e] & 0xFFFF0000u);
+                        }
+                    }
+                    if (EPI == GEMM_EPI_BIAS_GELU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
-                *reinterpret_cast<float4*>(a.C + off) = __builtin_bit_cast(float4, o);
+                        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+                    }
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+                    *reinterpret_cast<float4*>(a.C + rowoff + col0 + jn * 32) = __builtin_bit_cast(float4, o);
+                }
             }
         }
     };
+
+    DG(unsigned long long dL = 0, dA = 0, dM = 0, dB = 0, dE = 0, dt0 = stamp(), dt = dt0;)
+    // diagnostic barriers: time from segment start to barrier arrival, and time spent waiting in it
+    auto barA = [&]() { DG(unsigned long long t1 = stamp(); dL += t1 - dt;) bar(); DG(dt = stamp(); dA += dt - t1;) };
+    auto barB = [&]() { DG(unsigned long long t1 = stamp(); dM += t1 - dt;) bar(); DG(dt = stamp(); dB += dt - t1;) };
 
     // ---- prologue: half-tiles 0..5
     issue(0); issue(1); issue(2); issue(3);
@@ -292,41 +336,51 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
         // phase 0: quadrant (0, 0)
         ldW(0, lb + OFF_BF);
         stage_and_wait(2, as);
-        bar();
+        barA();
         mma(X0, 0, 0);
-        bar();
+        barB();
         // phase 1: quadrant (0, 1)
         ldW(1, lb + OFF_BS);
         stage_and_wait(3, as);
-        bar();
+        barA();
         mma(X0, 0, 1);
-        bar();
+        barB();
         // phase 2: quadrant (1, 1)
         ldX(X1, lb + OFF_AS);
         stage_and_wait(0, as);
-        bar();
+        barA();
         mma(X1, 1, 1);
-        bar();
+        barB();
         // phase 3: quadrant (1, 0); token fragments of the next K-step's quadrant row 0
         if (cs + 1 < total_stages) ldX(X0, smem + ((cs + 1) & 1) * BUF + OFF_AF);
         stage_and_wait(1, false);
-        bar();
+        barA();
         mma(X1, 1, 0);
         if (++c_t == KT) {
             // both groups write their tile in the same barrier interval
             c_t = 0;
+            DG(unsigned long long te = stamp(); dM += te - dt;)
             if (g == 1) epilogue();
+            DG(unsigned long long te1 = stamp();)
             bar();
+            DG(unsigned long long te2 = stamp();)
             if (g == 0) epilogue();
+            DG(dt = stamp(); dE += (te1 - te) + (dt - te2); dB += te2 - te1;)
             if (++c_j < n_my) {
                 coords(c_j, c_tm, c_tn);
                 init_acc();
             }
         } else {
-            bar();
+            barB();
         }
     }
     if (g == 0) bar();               // pairs with group 1's last barrier
+#ifdef GEMM_DIAG
+    if (a.dbg && lane == 0) {
+        unsigned long long* o = a.dbg + ((size_t)bid * 8 + wave) * 8;
+        o[0] = stamp() - dt0; o[1] = dL; o[2] = dA; o[3] = dM; o[4] = dB; o[5] = dE; o[6] = (unsigned long long)total_stages; o[7] = (dI << 32) | (dW & 0xFFFFFFFFull);
+    }
+#endif
 }
 
 }  // namespace
@@ -361,8 +415,36 @@ int launch_gemm_bf16(int epi, const void* A, const void* W, const float* bias, c
     const int ntiles = a.tiles_m * a.tiles_n;
     OTTER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int grid = std::min(ntiles, std::max(1, ncu));
+    a.dbg = nullptr;
+#ifdef GEMM_DIAG
+    static DevBuf dbgbuf;
+    const size_t dbg_n = (size_t)grid * 8 * 8;
+    { int rc = dbgbuf.reserve(dbg_n * 8); if (rc) return rc; }
+    OTTER_HIP_TRY(hipMemsetAsync(dbgbuf.p, 0, dbg_n * 8, st));
+    a.dbg = (unsigned long long*)dbgbuf.p;
+#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
     OTTER_HIP_TRY(hipGetLastError());
+#ifdef GEMM_DIAG
+    {
+        std::vector<unsigned long long> h(dbg_n);
+        OTTER_HIP_TRY(hipStreamSynchronize(st));
+        OTTER_HIP_TRY(hipMemcpy(h.data(), dbgbuf.p, dbg_n * 8, hipMemcpyDeviceToHost));
+        for (int grp = 0; grp < 2; ++grp) {
+            double t[7] = {0, 0, 0, 0, 0, 0, 0}, n = 0, tI = 0, tW = 0;
+            for (size_t i = 0; i < dbg_n; i += 8) {
+                if (!h[i] || (int)((i / 8) % 8) / 4 != grp) continue;
+                for (int k = 0; k < 7; ++k) t[k] += (double)h[i + k];
+                tI += (double)(h[i + 7] >> 32); tW += (double)(h[i + 7] & 0xFFFFFFFFull);
+                n += 1;
+            }
+            if (n > 0)
+                fprintf(stderr, "[gemm diag] epi=%d N=%d K=%d group %d: per K-step cycles total %.0f = load-seg %.0f + barA-wait %.0f + "
+                        "mfma-seg %.0f + barB-wait %.0f + epilogue %.0f  (stages/wg %.0f); in load-seg: dma issue %.0f vmcnt wait %.0f\n", epi, N, K, grp, t[0] / t[6],
+                        t[1] / t[6], t[2] / t[6], t[3] / t[6], t[4] / t[6], t[5] / t[6], t[6] / n, tI / t[6], tW / t[6]);
+        }
+    }
+#endif
     return OTTER_OK;
 }
 

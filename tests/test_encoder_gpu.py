@@ -102,3 +102,22 @@ def test_errors_are_loud():
     model.load_state_dict(sd, strict=False)
     with pytest.raises(ValueError):
         model({k: v.cuda() for k, v in batch.items()})          # wrong shape is refused by the library
+
+
+@pytest.mark.parametrize("B,L", [(3, 200), (2, 512), (5, 70), (1, 64), (2, 333)])
+def test_bf16_hidden_states_track_fp32_path(B, L):
+    # every valid row of the bf16 path's hidden state against the fp32 path of the same library
+    # (itself pinned to the reference fixtures above), after 1 and 2 layers, ragged batch:
+    # bf16 rounding gives ~1e-2 absolute error on O(1) activations; a wrong key, mask or tile
+    # shows as O(1).
+    cfg = R.make_config("roberta", layers=2, vocab_size=1000)
+    batch = R.make_batch(cfg, B, L, 31 + L)
+    m32 = _model(cfg, 11)
+    m16 = _model(cfg, 11, dtype="bf16")
+    valid = batch["input_mask"].numpy().astype(bool)
+    for n in (1, 2):
+        ref = m32.hidden_states(batch["input_ids"], batch["input_mask"], None, n).cpu().numpy()[valid]
+        got = m16.hidden_states(batch["input_ids"], batch["input_mask"], None, n).cpu().numpy()[valid]
+        err = np.abs(got - ref)
+        assert np.isfinite(got).all()
+        assert err.max() < 0.15 and err.mean() < 0.012, (n, float(err.max()), float(err.mean()))
