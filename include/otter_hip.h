@@ -93,8 +93,10 @@ int otter_index_set_id_base(otter_index* ix, int64_t id_base);
 void otter_index_destroy(otter_index* ix);
 
 /* Measurement hook (no counterpart in the reference; used by bench.py for the
- * roofline figure).  While enabled, search() brackets its scan kernel with HIP
- * events on the caller's stream.  otter_index_timing() waits for the recorded
+ * roofline figure).  While enabled, search() brackets its scan (the scan kernel
+ * and, for small query batches, the sample scan + sample merge ahead of it: every
+ * corpus byte is read inside the bracket exactly once) with HIP events on the
+ * caller's stream.  otter_index_timing() waits for the recorded
  * events and returns the summed scan-kernel time and the number of launches
  * since the previous call (at most 4096 launches are kept between calls). */
 int otter_index_set_timing(otter_index* ix, int enable);

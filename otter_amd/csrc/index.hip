@@ -96,7 +96,9 @@ struct ScanArgs {
     int k;
     int qtiles;         // nq_pad / BQ
     int strips;         // S
-    int total_tiles;    // ceil(n / BM)
+    int total_tiles;    // tiles scanned by this launch
+    int tile_begin;     // first tile (rows below tile_begin * BM belong to the sample pass)
+    const u32* thr0;    // [nq_pad] initial score-key threshold per query (null: none)
     u64* dbg;           // SCAN_DIAG builds only: per-wave cycle sums {total, stage wait, epilogue, stages}
 };
 
@@ -129,6 +131,7 @@ __device__ __forceinline__ u64 wave_compact(u64* base, int n, int k, int lane) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) cntv += __popcll(__ballot(x[e] >= c));
         if (cntv >= k) T = c;
+        if (cntv == k) break;   // exactly k composites are >= T: T selects the same set as the k-th largest
     }
     int off = 0;
 #pragma unroll
@@ -190,13 +193,15 @@ __global__ __launch_bounds__(WM * WQ * 64, WM * WQ / 4) void scan_kernel(ScanArg
     const int qt = wg / a.strips;
     const int strip = wg - qt * a.strips;
     const int q0 = qt * BQ;
-    const int t0 = (int)(((long long)strip * a.total_tiles) / a.strips);
-    const int t1 = (int)(((long long)(strip + 1) * a.total_tiles) / a.strips);
+    const int t0 = a.tile_begin + (int)(((long long)strip * a.total_tiles) / a.strips);
+    const int t1 = a.tile_begin + (int)(((long long)(strip + 1) * a.total_tiles) / a.strips);
     const int KS = a.ld / BK;
 
     for (int i = tid; i < BQ; i += NT) {
         sCnt[i] = 0;
-        sThr[i] = (q0 + i < a.nq) ? 0u : 0xFFFFFFFFu;  // padded queries never accept
+        // padded queries never accept; a sample pass may have left the score key of each query's
+        // k-th best among rows with smaller ids: only strictly larger keys can still enter its top k
+        sThr[i] = (q0 + i < a.nq) ? (a.thr0 ? a.thr0[q0 + i] : 0u) : 0xFFFFFFFFu;
     }
     if (tid == 0) *sFlag = 0;
 
@@ -435,15 +440,22 @@ struct MergeArgs {
     int fan;             // strips merged by one workgroup
     int nq_pad;
     int k;
-    int npad;            // power of two >= fan * min(cap_in, k)
+    int npad;            // power of two >= fan * min(cap_in, k) (+ k with an extra list)
     int final_level;
+    const u64* ex;       // final level only: one more sorted list [nq_pad][k] (the sample pass), or null
+    const u32* ex_cnt;   // [nq_pad]
+    u32* thr_out;        // non-final level with one group: [nq_pad] key of the k-th best, 0 if fewer than k
 };
 
-__device__ __forceinline__ void bitonic_desc_u64(u64* l, int n, int tid) {
+constexpr int MAX_SELECT = 8192;       // composites one merge workgroup selects from in LDS
+constexpr int MERGE_THREADS = 1024;
+constexpr int MERGE_MAX_STRIPS = 1024;   // strips one merge workgroup gathers (host keeps fan below it)
+
+__device__ __forceinline__ void bitonic_desc_u64(u64* l, int n, int tid, int nthreads) {
     for (int size = 2; size <= n; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             __syncthreads();
-            for (int i = tid; i < (n >> 1); i += NTHREADS) {
+            for (int i = tid; i < (n >> 1); i += nthreads) {
                 const int lo = 2 * i - (i & (stride - 1));
                 const int hi = lo + stride;
                 const bool desc = (lo & size) == 0;
@@ -455,36 +467,110 @@ __device__ __forceinline__ void bitonic_desc_u64(u64* l, int n, int tid) {
     __syncthreads();
 }
 
-__global__ __launch_bounds__(NTHREADS) void merge_kernel(MergeArgs a) {
+// One workgroup merges the candidate lists of up to `fan` strips of one query: counts are read
+// in parallel and prefix-summed in LDS (no chain of dependent global loads), one wave copies one
+// strip at a time, and only the live power-of-two prefix is sorted.
+__global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(MergeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* l = reinterpret_cast<u64*>(smem);
+    int* sOff = reinterpret_cast<int*>(smem + (size_t)a.npad * sizeof(u64));   // [ns + 2]
     const int q = blockIdx.x;
     const int g = blockIdx.y;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s0 = g * a.fan;
-    const int s1 = min(a.S_in, s0 + a.fan);
-    int off = 0;
-    for (int s = s0; s < s1; ++s) {
-        int c = (int)a.in_cnt[(size_t)s * a.nq_pad + q];
-        c = min(c, a.k);
-        const u64* src = a.in + ((size_t)s * a.nq_pad + q) * a.cap_in;
-        for (int i = tid; i < c; i += NTHREADS) l[off + i] = src[i];
-        off += c;
+    const int ns = min(a.S_in, s0 + a.fan) - s0;
+    const bool extra = a.final_level && a.ex;
+    for (int t = tid; t < ns + (extra ? 1 : 0); t += MERGE_THREADS) {
+        const int c = t < ns ? (int)a.in_cnt[(size_t)(s0 + t) * a.nq_pad + q] : (int)a.ex_cnt[q];
+        sOff[t + 1] = min(c, a.k);
     }
-    for (int i = off + tid; i < a.npad; i += NTHREADS) l[i] = 0ull;
-    bitonic_desc_u64(l, a.npad, tid);
+    __syncthreads();
+    if (wave == 0) {   // inclusive scan of <= MERGE_MAX_STRIPS + 1 counts by one wave
+        int run = 0;
+        const int n = ns + (extra ? 1 : 0);
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            int v = c0 + lane < n ? sOff[c0 + lane + 1] : 0;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int u = __shfl_up(v, o);
+                if (lane >= o) v += u;
+            }
+            if (c0 + lane < n) sOff[c0 + lane + 1] = run + v;
+            run += __shfl(v, 63);
+        }
+        if (lane == 0) sOff[0] = 0;
+    }
+    __syncthreads();
+    const int nlist = ns + (extra ? 1 : 0);
+    const int off = sOff[nlist];
+    for (int t = wave; t < nlist; t += MERGE_THREADS / 64) {
+        const int o0 = sOff[t], c = sOff[t + 1] - o0;
+        const u64* src = t < ns ? a.in + ((size_t)(s0 + t) * a.nq_pad + q) * a.cap_in : a.ex + (size_t)q * a.k;
+        for (int i = lane; i < c; i += 64) l[o0 + i] = src[i];
+    }
+    __syncthreads();
+    // Block-wide radix select of the k largest (composites are unique and non-zero): every thread
+    // keeps its <= MAX_SELECT / MERGE_THREADS elements in registers, one ballot count per bit,
+    // stop as soon as exactly k remain; only the survivors are sorted.
+    constexpr int EPT = MAX_SELECT / MERGE_THREADS;
+    u64 x[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int idx = e * MERGE_THREADS + tid;
+        x[e] = idx < off ? l[idx] : 0ull;
+    }
+    u64 T = 1ull;                               // off <= k: keep every gathered composite
+    int* sW = sOff + MERGE_MAX_STRIPS + 4;      // [2][16] per-wave counts, double buffered by round
+    int* sPos = sW + 32;
+    if (off > a.k) {
+        T = 0ull;
+        int par = 0;
+        for (int b = 63; b >= 0; --b, par ^= 1) {
+            const u64 c = T | (1ull << b);
+            int cw = 0;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) cw += __popcll(__ballot(x[e] >= c));
+            if (lane == 0) sW[par * 16 + wave] = cw;
+            __syncthreads();
+            int cntv = 0;
+#pragma unroll
+            for (int w = 0; w < MERGE_THREADS / 64; ++w) cntv += sW[par * 16 + w];
+            if (cntv >= a.k) T = c;
+            if (cntv == a.k) break;             // uniform: every thread sees the same counts
+        }
+    }
+    if (tid == 0) *sPos = 0;
+    __syncthreads();                            // every thread holds its elements: l may be overwritten
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const bool keep = x[e] >= T && x[e] != 0ull;
+        const u64 m = __ballot(keep);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(sPos, __popcll(m));
+        base = __shfl(base, 0);
+        if (keep) l[base + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0))] = x[e];
+    }
+    __syncthreads();
+    const int kept = *sPos;                     // == min(off, k)
+    int npad = 2;
+    while (npad < kept) npad <<= 1;             // <= next_pow2(k) <= a.npad
+    for (int i = kept + tid; i < npad; i += MERGE_THREADS) l[i] = 0ull;
+    bitonic_desc_u64(l, npad, tid, MERGE_THREADS);
     const int total = min(off, a.k);
     if (a.final_level) {
-        for (int t = tid; t < a.k; t += NTHREADS) {
-            const u64 e = l[t];
+        for (int t = tid; t < a.k; t += MERGE_THREADS) {
+            const u64 e = t < total ? l[t] : 0ull;
             const bool valid = t < total;
             a.D[(size_t)q * a.k + t] = valid ? key2f((u32)(e >> 32)) : -FLT_MAX;
             a.I[(size_t)q * a.k + t] = valid ? a.id_base + (long long)(0xFFFFFFFFu - (u32)e) : -1ll;
         }
     } else {
         u64* dst = a.out + ((size_t)g * a.nq_pad + q) * a.k;
-        for (int t = tid; t < total; t += NTHREADS) dst[t] = l[t];
-        if (tid == 0) a.out_cnt[(size_t)g * a.nq_pad + q] = (u32)total;
+        for (int t = tid; t < total; t += MERGE_THREADS) dst[t] = l[t];
+        if (tid == 0) {
+            a.out_cnt[(size_t)g * a.nq_pad + q] = (u32)total;
+            if (a.thr_out) a.thr_out[q] = total >= a.k ? (u32)(l[a.k - 1] >> 32) : 0u;
+        }
     }
 }
 
@@ -548,7 +634,6 @@ __global__ __launch_bounds__(NTHREADS) void pair_merge_kernel(PairMergeArgs a) {
 
 // ------------------------------------------------------------------ host side
 
-constexpr int MAX_SELECT = 8192;       // composites one merge workgroup sorts in LDS
 constexpr long long QCHUNK = 16384;    // queries per scan launch (bounds scratch)
 
 struct ScanCfg {
@@ -620,7 +705,7 @@ struct otter_index {
     int d = 0, ld = 0, dtype = OTTER_F32, device = 0, ncu = 256;
     long long n = 0, cap_rows = 0, id_base = 0;
     float* x = nullptr;
-    otter::DevBuf qpad, cand, cnt, lvl[2], lvlcnt[2], io_q, io_D, io_I;
+    otter::DevBuf qpad, cand, cnt, lvl[2], lvlcnt[2], smp, smpcnt, thr0, io_q, io_D, io_I;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
 };
@@ -656,6 +741,69 @@ int index_reserve_rows(otter_index* ix, long long need_rows, hipStream_t st) {
     return OTTER_OK;
 }
 
+// Merge the per-strip candidate lists of one scan, level by level (one workgroup sorts at most
+// MAX_SELECT composites).  final: write (D, I), optionally merging one more sorted list (ex);
+// otherwise leave ONE sorted list of <= k composites per query in list_out and the score key of
+// each query's k-th best in thr_out.
+int run_merge(otter_index* ix, const u64* in, const u32* in_cnt, int cap_in, int S_in, long long nq, long long nq_pad,
+              int k, bool final, float* D, long long* I, const u64* ex, const u32* ex_cnt, u64* list_out,
+              u32* list_cnt, u32* thr_out, hipStream_t st) {
+    const int fan = std::min(MERGE_MAX_STRIPS, std::max(2, MAX_SELECT / k - (ex ? 1 : 0)));
+    int pp = 0, rc;
+    for (;;) {
+        const int S_out = (S_in + fan - 1) / fan;
+        const bool last = S_out == 1;
+        MergeArgs ma;
+        ma.in = in;
+        ma.in_cnt = in_cnt;
+        ma.out = nullptr;
+        ma.out_cnt = nullptr;
+        ma.D = D;
+        ma.I = I;
+        ma.id_base = ix->id_base;
+        ma.cap_in = cap_in;
+        ma.S_in = S_in;
+        ma.fan = fan;
+        ma.nq_pad = (int)nq_pad;
+        ma.k = k;
+        ma.final_level = (last && final) ? 1 : 0;
+        ma.ex = ma.final_level ? ex : nullptr;
+        ma.ex_cnt = ma.final_level ? ex_cnt : nullptr;
+        ma.thr_out = nullptr;
+        ma.npad = next_pow2(std::max(2, (std::min(S_in, fan) + (ma.ex ? 1 : 0)) * k));
+        ma.npad = std::max(ma.npad, next_pow2(k));
+        if (!ma.final_level) {
+            if (last) {
+                ma.out = list_out;
+                ma.out_cnt = list_cnt;
+                ma.thr_out = thr_out;
+            } else {
+                if ((rc = ix->lvl[pp].reserve((size_t)S_out * nq_pad * k * sizeof(u64)))) return rc;
+                if ((rc = ix->lvlcnt[pp].reserve((size_t)S_out * nq_pad * sizeof(u32)))) return rc;
+                ma.out = (u64*)ix->lvl[pp].p;
+                ma.out_cnt = (u32*)ix->lvlcnt[pp].p;
+            }
+        }
+        const size_t lds = (size_t)ma.npad * sizeof(u64) + (size_t)(MERGE_MAX_STRIPS + 4 + 32 + 4) * sizeof(int);
+        static bool attr_set[64] = {};
+        if (ix->device < 64 && !attr_set[ix->device]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(merge_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      MAX_SELECT * 2 * (int)sizeof(u64) + (MERGE_MAX_STRIPS + 40) * (int)sizeof(int));
+            attr_set[ix->device] = true;
+        }
+        hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq, (unsigned)S_out), dim3(MERGE_THREADS), lds, st, ma);
+        OTTER_HIP_TRY(hipGetLastError());
+        if (last) break;
+        in = ma.out;
+        in_cnt = ma.out_cnt;
+        cap_in = k;
+        S_in = S_out;
+        pp ^= 1;
+    }
+    return OTTER_OK;
+}
+
 // one scan + merge over queries [qd, qd + nq) (device pointers), results to device D/I
 int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st) {
     ScanCfg cfg;
@@ -663,13 +811,32 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
     if (rc) return rc;
     const long long nq_pad = round_up64(nq, cfg.bq);
     const int qtiles = (int)(nq_pad / cfg.bq);
-    const int total_tiles = (int)((ix->n + cfg.bm - 1) / cfg.bm);
+    const int all_tiles = (int)((ix->n + cfg.bm - 1) / cfg.bm);
+
+    // Sample pass (small query batches on large corpora): every strip otherwise re-learns its own
+    // top-k threshold, appending ~k ln(rows/k) candidates per query and strip.  Scanning the first
+    // n_s rows first and merging them gives each query the key of its k-th best among rows
+    // [0, n_s); the main scan over [n_s, n) starts every strip from that threshold.  Exact: the
+    // sample rows have the smallest ids, so a later row that only ties the k-th key ranks behind it.
+    static const char* no_sample = getenv("OTTER_NO_SAMPLE");
+    const long long n_s = round_up64(std::max<long long>(16384, 64ll * k), 256);
+    const bool sample = !no_sample && nq <= 64 && ix->n >= 12 * n_s;
+    const int sample_tiles = sample ? (int)(n_s / cfg.bm) : 0;
+
+    const int main_tiles = all_tiles - sample_tiles;
     int strips = std::max(1, ix->ncu / qtiles);
-    strips = std::min(strips, total_tiles);
+    strips = std::min(strips, main_tiles);
+    // few enough sample strips for a one-level merge (k <= 128 on this path's sizes: fan >= 64)
+    int strips_s = sample ? std::min(std::min(std::max(1, ix->ncu / qtiles), sample_tiles), 64) : 0;
 
     if ((rc = ix->qpad.reserve((size_t)nq_pad * ix->ld * sizeof(float)))) return rc;
-    if ((rc = ix->cand.reserve((size_t)strips * nq_pad * cfg.cap * sizeof(u64)))) return rc;
-    if ((rc = ix->cnt.reserve((size_t)strips * nq_pad * sizeof(u32)))) return rc;
+    if ((rc = ix->cand.reserve((size_t)std::max(strips, strips_s) * nq_pad * cfg.cap * sizeof(u64)))) return rc;
+    if ((rc = ix->cnt.reserve((size_t)std::max(strips, strips_s) * nq_pad * sizeof(u32)))) return rc;
+    if (sample) {
+        if ((rc = ix->smp.reserve((size_t)nq_pad * k * sizeof(u64)))) return rc;
+        if ((rc = ix->smpcnt.reserve((size_t)nq_pad * sizeof(u32)))) return rc;
+        if ((rc = ix->thr0.reserve((size_t)nq_pad * sizeof(u32)))) return rc;
+    }
 
     {
         const long long total = nq_pad * ix->ld;
@@ -689,16 +856,7 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
     sa.nq_pad = (int)nq_pad;
     sa.k = k;
     sa.qtiles = qtiles;
-    sa.strips = strips;
-    sa.total_tiles = total_tiles;
     sa.dbg = nullptr;
-#ifdef SCAN_DIAG
-    static otter::DevBuf dbgbuf;
-    const size_t dbg_n = (size_t)qtiles * strips * 8 * 4;
-    if ((rc = dbgbuf.reserve(dbg_n * sizeof(u64)))) return rc;
-    OTTER_HIP_TRY(hipMemsetAsync(dbgbuf.p, 0, dbg_n * sizeof(u64), st));
-    sa.dbg = (u64*)dbgbuf.p;
-#endif
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     const bool timed = ix->timing && ix->ev_pending.size() < 4096;
     if (timed) {
@@ -711,6 +869,29 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
         }
         OTTER_HIP_TRY(hipEventRecord(ev.first, st));
     }
+    if (sample) {
+        sa.strips = strips_s;
+        sa.total_tiles = sample_tiles;
+        sa.tile_begin = 0;
+        sa.thr0 = nullptr;
+        cfg.launch(sa, qtiles * strips_s, cfg.lds, st);
+        OTTER_HIP_TRY(hipGetLastError());
+        if ((rc = run_merge(ix, (const u64*)ix->cand.p, (const u32*)ix->cnt.p, cfg.cap, strips_s, nq, nq_pad, k, false,
+                            nullptr, nullptr, nullptr, nullptr, (u64*)ix->smp.p, (u32*)ix->smpcnt.p, (u32*)ix->thr0.p,
+                            st)))
+            return rc;
+    }
+    sa.strips = strips;
+    sa.total_tiles = main_tiles;
+    sa.tile_begin = sample_tiles;
+    sa.thr0 = sample ? (const u32*)ix->thr0.p : nullptr;
+#ifdef SCAN_DIAG
+    static otter::DevBuf dbgbuf;
+    const size_t dbg_n = (size_t)qtiles * strips * 8 * 4;
+    if ((rc = dbgbuf.reserve(dbg_n * sizeof(u64)))) return rc;
+    OTTER_HIP_TRY(hipMemsetAsync(dbgbuf.p, 0, dbg_n * sizeof(u64), st));
+    sa.dbg = (u64*)dbgbuf.p;
+#endif
     cfg.launch(sa, qtiles * strips, cfg.lds, st);
     OTTER_HIP_TRY(hipGetLastError());
     if (timed) {
@@ -734,56 +915,9 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
                     nwv, tot / nwv, mx, wait / nwv, epi / nwv, tot / stages, wait / stages);
     }
 #endif
-
-    // merge levels: S strips -> 1
-    const int fan = std::max(2, MAX_SELECT / k);
-    const u64* in = (const u64*)ix->cand.p;
-    const u32* in_cnt = (const u32*)ix->cnt.p;
-    int cap_in = cfg.cap;
-    int S_in = strips;
-    int pp = 0;
-    for (;;) {
-        const int S_out = (S_in + fan - 1) / fan;
-        const bool fin = S_out == 1;
-        MergeArgs ma;
-        ma.in = in;
-        ma.in_cnt = in_cnt;
-        ma.out = nullptr;
-        ma.out_cnt = nullptr;
-        ma.D = D;
-        ma.I = I;
-        ma.id_base = ix->id_base;
-        ma.cap_in = cap_in;
-        ma.S_in = S_in;
-        ma.fan = fan;
-        ma.nq_pad = (int)nq_pad;
-        ma.k = k;
-        ma.npad = next_pow2(std::max(2, std::min(S_in, fan) * k));
-        ma.npad = std::max(ma.npad, next_pow2(k));
-        ma.final_level = fin ? 1 : 0;
-        if (!fin) {
-            if ((rc = ix->lvl[pp].reserve((size_t)S_out * nq_pad * k * sizeof(u64)))) return rc;
-            if ((rc = ix->lvlcnt[pp].reserve((size_t)S_out * nq_pad * sizeof(u32)))) return rc;
-            ma.out = (u64*)ix->lvl[pp].p;
-            ma.out_cnt = (u32*)ix->lvlcnt[pp].p;
-        }
-        const size_t lds = (size_t)ma.npad * sizeof(u64);
-        static bool attr_set[64] = {};
-        if (ix->device < 64 && !attr_set[ix->device]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(merge_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, MAX_SELECT * 2 * (int)sizeof(u64));
-            attr_set[ix->device] = true;
-        }
-        hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq, (unsigned)S_out), dim3(NTHREADS), lds, st, ma);
-        OTTER_HIP_TRY(hipGetLastError());
-        if (fin) break;
-        in = ma.out;
-        in_cnt = ma.out_cnt;
-        cap_in = k;
-        S_in = S_out;
-        pp ^= 1;
-    }
-    return OTTER_OK;
+    return run_merge(ix, (const u64*)ix->cand.p, (const u32*)ix->cnt.p, cfg.cap, strips, nq, nq_pad, k, true, D, I,
+                     sample ? (const u64*)ix->smp.p : nullptr, sample ? (const u32*)ix->smpcnt.p : nullptr, nullptr,
+                     nullptr, nullptr, st);
 }
 
 // n == 0: every result is padding
@@ -947,6 +1081,9 @@ void otter_index_destroy(otter_index* ix) {
     ix->cand.release();
     ix->cnt.release();
     for (int i = 0; i < 2; ++i) { ix->lvl[i].release(); ix->lvlcnt[i].release(); }
+    ix->smp.release();
+    ix->smpcnt.release();
+    ix->thr0.release();
     ix->io_q.release();
     ix->io_D.release();
     ix->io_I.release();

@@ -44,6 +44,11 @@ CASES = [
     (20000, 768, 130, 2048),
     (300, 768, 5, 129),
     (70000, 64, 32, 500),
+    # >= 32 * 16384 rows and <= 64 queries: the sample pass seeds every strip's threshold
+    (600000, 768, 5, 100),
+    (540000, 128, 40, 200),
+    (530000, 64, 1, 1),
+    (530000, 64, 64, 256),
 ]
 
 
@@ -95,6 +100,26 @@ def test_ties_duplicate_rows_and_all_equal():
     xb[::2] *= -1.0                                       # -0.0 rows tie with +0.0 rows
     D, I = _search(xb, q, 10)
     np.testing.assert_array_equal(I, np.tile(np.arange(10), (3, 1)))
+
+
+def test_sample_pass_ties_across_the_sample_boundary():
+    # duplicates of the best rows sit on both sides of the sample boundary (row 16384) and all
+    # scores of a block are equal: the seeded threshold must keep (score desc, id asc) exact
+    rng = np.random.RandomState(17)
+    n, d = 540000, 64
+    xb = (rng.randn(n, d) * 0.1).astype(np.float32)
+    q = rng.randn(9, d).astype(np.float32)
+    best = (q[:3] * 4.0).astype(np.float32)
+    for j, r in enumerate((5, 16383, 16384, 20000, 300000, 539999)):
+        xb[r] = best[j % 3]                       # same top rows in the sample and in the main scan
+    xb[100000:100300] = xb[7]                     # 300 exact copies of a sample row, far in the main scan
+    D, I = _search(xb, q, 100)
+    Dr, Ir = flat_ip.search_c(xb, q, 100, mode=flat_ip.MODE_GPU_ORDER)
+    np.testing.assert_array_equal(I, Ir)
+    np.testing.assert_array_equal(D.view(np.uint32), Dr.view(np.uint32))
+    xb[:] = 1.0                                   # every score equal: ids 0..k-1
+    D, I = _search(xb, np.ones((3, d), np.float32), 50)
+    np.testing.assert_array_equal(I, np.tile(np.arange(50), (3, 1)))
 
 
 def test_negative_and_infinite_scores():
