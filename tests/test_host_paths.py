@@ -1,0 +1,140 @@
+"""CPU tests of the host-side "next" rows against fixtures produced by the REFERENCE's
+own functions (oracle/gen_host_goldens.py -> tests/golden/host_*.json, tests/golden/toy_tokenizer/):
+feature builder + mask rule + collate, string metrics, recall arithmetic, id2doc / embedding formats."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from otter_amd import eval_driver as EV
+from otter_amd import features as F
+from otter_amd.encode_driver import em_collate_bert
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def feats():
+    with open(os.path.join(GOLD, "host_features.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def metrics():
+    with open(os.path.join(GOLD, "host_metrics.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def tokenizer():
+    from transformers import PreTrainedTokenizerFast
+    return PreTrainedTokenizerFast.from_pretrained(os.path.join(GOLD, "toy_tokenizer"))
+
+
+def test_feature_builder_and_collate_match_reference(feats, tokenizer):
+    from types import SimpleNamespace
+    for case in feats["cases"]:
+        args = SimpleNamespace(max_c_len=case["max_c_len"], max_q_len=case["max_q_len"],
+                               normalize_table=case["normalize_table"], one_query=True, no_passages=False,
+                               psg_mode="ori")
+        data = feats["corpus"] if case["table"] else feats["questions"]
+        ds = F.EmDatasetMetaThreeCat(tokenizer, data, case["table"], args)
+        batch = em_collate_bert([ds[i] for i in range(len(ds))], pad_id=tokenizer.pad_token_id)
+        assert set(batch) == set(case["batch"])
+        for k, v in case["batch"].items():
+            exp = torch.tensor(v)
+            assert batch[k].dtype == torch.int64 and tuple(batch[k].shape) == tuple(exp.shape), k
+            assert torch.equal(batch[k], exp), (k, case["max_c_len"], case["table"])
+        if case["strings"] is not None:
+            fn = F.convert_tb_to_string_metadata_norm if case["normalize_table"] else F.convert_tb_to_string_metadata
+            got = [list(fn(d["table"], d["passages"][:8], d["meta_data"])) for d in data]
+            assert got == case["strings"]
+
+
+def test_mask_rule_on_synthetic_special_token_masks():
+    # <s> A A A </s> </s> B B </s> <pad> <pad>: part2 = tokens of A, part3 = tokens of B
+    stm = [1, 0, 0, 0, 1, 1, 0, 0, 1, 1, 1]
+    p2, p3 = F.threecat_masks(stm, question=False)
+    assert p2.tolist() == [0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0]
+    assert p3.tolist() == [0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0]
+    # question: <s> Q Q </s> <pad>: part3 == part2
+    p2, p3 = F.threecat_masks([1, 0, 0, 1, 1], question=True)
+    assert p2.tolist() == [0, 1, 1, 0, 0] and p3.tolist() == p2.tolist()
+    # empty second segment: <s> A </s> </s> </s>: part3 is empty (the encoder's 'first' pooling then takes row 0)
+    p2, p3 = F.threecat_masks([1, 0, 1, 1, 1], question=False)
+    assert p2.tolist() == [0, 1, 0, 0, 0] and p3.sum() == 0
+
+
+def test_string_metrics_match_reference(metrics):
+    tok = EV.SimpleTokenizer()
+    blocks = metrics["blocks"]
+    for w in metrics["words"]:
+        assert tok.words(EV.normalize(w["text"]), uncased=True) == w["words"]
+    for c in metrics["para_has_answer"]:
+        assert EV.para_has_answer(c["answer"], blocks[c["lo"]:c["hi"]], tok) == c["para_has_answer"], c["answer"]
+    for c in metrics["found_table"]:
+        assert EV.found_table(c["gold"], blocks[c["lo"]:c["hi"]]) == c["found_table"], c["gold"]
+    assert any(c["para_has_answer"] for c in metrics["para_has_answer"])
+    assert any(not c["para_has_answer"] for c in metrics["para_has_answer"])
+
+
+def test_records_recall_and_jsonl(tmp_path, metrics):
+    blocks = metrics["blocks"]
+    id2doc = {str(i): b for i, b in enumerate(blocks)}
+    ds_items = [{"question_id": "q%d" % i, "question": "what %d?" % i, "table_id": blocks[i]["table_id"],
+                 "answer-text": blocks[i]["table"][1][0][1], "type": "single" if i % 2 else "multi"} for i in range(4)]
+    beam = 5
+    I = np.array([[0, 1, 2, 3, 4], [4, 1, 0, 2, 3], [5, 6, 7, 8, 9], [9, 8, 3, 6, 5]], np.int64)
+    m, o = EV.records(ds_items, I, id2doc, beam, eval_only_ans=True, with_outputs=True)
+    assert [x["table_recall"] for x in m] == [1, 1, 0, 1]
+    # (the reference joins passages, header and row WITHOUT separators, retrieval/utils/utils.py:143-145, so a
+    # first-cell answer fuses with the last header word; a second-cell answer is found)
+    assert [x["ans_recall"] for x in m] == [1, 1, int(EV.para_has_answer(ds_items[2]["answer-text"], blocks[5:10],
+                                                                          EV.SimpleTokenizer())), 1]
+    assert list(o[0].keys()) == ["question_id", "question", "top_5", "answer-text", "table_id"]
+    assert [t["table_id"] for t in o[1]["top_5"]] == [blocks[j]["table_id"] for j in I[1]]
+    rep = EV.table_recall_report(o, "top_5")
+    # labels as the reference prints them: n=3 is reported as "@5", n=25 as "@50"
+    assert [r[0] for r in rep] == ["1", "5", "10", "15", "20", "50", "100"]
+    by = {r[0]: r for r in rep}
+    assert by["1"][1:] == (0.25, 1, 4)            # only question 0 has its table first
+    assert by["5"][1:] == (0.75, 3, 4)            # within the first THREE: questions 0, 1 (row 1), 3 (row 2)
+    assert by["100"][1:] == (0.75, 3, 4)
+    a = EV.answer_recall_report(m)
+    assert a["table_recall"] == 0.75 and set(a["types"]) == {"single", "multi"}
+    p = tmp_path / "out.jsonl"
+    EV.write_jsonl(str(p), o)
+    back = [json.loads(line) for line in open(p)]
+    assert back == o
+    # legacy id2doc ([title, text] lists) is converted as the reference does
+    lp = tmp_path / "id2doc.json"
+    json.dump({"0": ["T", "x"], "1": ["U", "y"]}, open(lp, "w"))
+    assert EV.load_id2doc(str(lp))["1"] == {"title": "U", "text": "y"}
+
+
+def test_id2doc_and_embedding_formats(tmp_path, feats):
+    corpus = feats["corpus"]
+    path = tmp_path / "emb" / "id2doc.json"
+    F.write_id2doc(str(path), corpus)
+    id2doc = json.load(open(path))
+    assert len(id2doc) == len(corpus)
+    d3 = id2doc["3"]
+    assert list(d3.keys()) == ["table_id", "row_id", "table", "meta_data", "passages_id", "passages"]
+    assert d3["table"] == corpus[3]["table"] and d3["passages"] == corpus[3]["passages"]
+    # embeddings: reference .npy and the row-sharded store written by the data-parallel encode
+    rng = np.random.RandomState(0)
+    full = rng.randn(10, 6).astype(np.float32)
+    np.save(tmp_path / "all.npy", full)
+    assert np.array_equal(np.asarray(F.open_embeddings(str(tmp_path / "all.npy"))), full)
+    bounds = [(0, 4), (4, 8), (8, 10)]
+    for r, (lo, hi) in enumerate(bounds):
+        F.write_embedding_shards(str(tmp_path / "sh" / "corpus"), torch.from_numpy(full[lo:hi]), lo, 3, r)
+    shards = F.open_embedding_shards(str(tmp_path / "sh" / "corpus"))
+    assert [s[0] for s in shards] == [0, 4, 8]
+    assert np.array_equal(np.concatenate([np.asarray(s[1]) for s in shards]), full)
+    os.remove(tmp_path / "sh" / "corpus.shard00001.npy")
+    os.remove(tmp_path / "sh" / "corpus.shard00001.json")
+    with pytest.raises(ValueError):
+        F.open_embedding_shards(str(tmp_path / "sh" / "corpus"))
