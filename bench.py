@@ -171,6 +171,12 @@ def main():
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per scan launch from a separate rocprofv3 --pmc pass (profiles/)")
     args = ap.parse_args()
+    if args.traffic_bytes is None and (args.rows, args.dim, args.nq, args.k) == (1000000, 768, 2214, 100):
+        # HBM-side bytes per scan launch from this round's separate rocprofv3 --pmc passes (profiles/)
+        tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tp):
+            with open(tp) as f:
+                args.traffic_bytes = float(json.load(f)["scan_kernel_hbm_bytes_per_launch"])
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

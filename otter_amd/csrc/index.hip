@@ -99,6 +99,7 @@ struct ScanArgs {
     int total_tiles;    // tiles scanned by this launch
     int tile_begin;     // first tile (rows below tile_begin * BM belong to the sample pass)
     const u32* thr0;    // [nq_pad] initial score-key threshold per query (null: none)
+    int order;          // 0: strip fastest within an XCD's range, 1: query tile fastest (speed only)
     u64* dbg;           // SCAN_DIAG builds only: per-wave cycle sums {total, stage wait, epilogue, stages}
 };
 
@@ -190,8 +191,14 @@ __global__ __launch_bounds__(WM * WQ * 64, WM * WQ / 4) void scan_kernel(ScanArg
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         wg = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
     }
-    const int qt = wg / a.strips;
-    const int strip = wg - qt * a.strips;
+    int qt, strip;
+    if (a.order) {   // workgroups of an XCD walk the same corpus strips for different query tiles: rows hit in L2
+        strip = wg / a.qtiles;
+        qt = wg - strip * a.qtiles;
+    } else {
+        qt = wg / a.strips;
+        strip = wg - qt * a.strips;
+    }
     const int q0 = qt * BQ;
     const int t0 = a.tile_begin + (int)(((long long)strip * a.total_tiles) / a.strips);
     const int t1 = a.tile_begin + (int)(((long long)(strip + 1) * a.total_tiles) / a.strips);
@@ -857,6 +864,8 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
     sa.k = k;
     sa.qtiles = qtiles;
     sa.dbg = nullptr;
+    static const char* ord = getenv("OTTER_SCAN_ORDER");
+    sa.order = ord ? (ord[0] == '1') : 1;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     const bool timed = ix->timing && ix->ev_pending.size() < 4096;
     if (timed) {
