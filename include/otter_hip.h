@@ -63,6 +63,10 @@ typedef struct otter_index otter_index;
  * dtype = storage type of the corpus in HBM (OTTER_F32: exact IndexFlatIP
  * arithmetic in fp32).  The index lives on HIP device `device`. */
 int otter_index_create(int d, int dtype, int device, otter_index** out);
+/* dtype OTTER_BF16 (no counterpart in the reference; BASELINE's 100M-row configuration): rows are
+ * rounded to bfloat16 on add(), queries on search(); scores are accumulated in float32 and are
+ * NOT IndexFlatIP's float32 scores (reported separately: recall@k against the OTTER_F32 index).
+ * k <= 1024 for this storage type. */
 
 /* index.add(xb) — scripts/eval_ottqa_retrieval.py:109.
  * x: float32 row-major [n, d], host (x_is_device = 0) or device pointer.
@@ -101,6 +105,13 @@ void otter_index_destroy(otter_index* ix);
  * since the previous call (at most 4096 launches are kept between calls). */
 int otter_index_set_timing(otter_index* ix, int enable);
 int otter_index_timing(otter_index* ix, double* scan_ms, int64_t* scan_launches);
+
+/* Diagnostic (no counterpart in the reference).  Large query batches on an OTTER_F32 index run a
+ * coarse pass on the bf16 matrix cores (hi/lo split of both operands), re-score its k + margin
+ * candidates with the exact float32 chain and PROVE per query that no other row can reach the top
+ * k; a query without a proof is searched again by the exact float32 kernel.  Returns how many
+ * queries of the last search() took that second route (0 in the usual case). */
+int64_t otter_index_last_fallback(const otter_index* ix);
 
 /* Final merge of the row-sharded search: G sorted candidate lists per query
  * (Dc float32 [G, nq, k], Ic int64 [G, nq, k], device pointers, as returned

@@ -421,6 +421,417 @@ __global__ __launch_bounds__(WM * WQ * 64, WM * WQ / 4) void scan_kernel(ScanArg
     for (int i = tid; i < BQ; i += NT) a.cnt[(size_t)strip * a.nq_pad + q0 + i] = sCnt[i];
 }
 
+// ------------------------------------------------------------------ bf16-MFMA scan
+// Same product, on the bf16 matrix cores (16x the fp32 matrix rate).  Two uses:
+//   MODE 0  corpus stored as bf16 (dtype OTTER_BF16; BASELINE config 5): rows are [ld] bf16,
+//           queries rounded to bf16, score = sum over k of x_k q_k accumulated in fp32.
+//   MODE 1  coarse pass of the exact fp32 search: every fp32 value v is split into
+//           hi = bf16(v), lo = bf16(v - hi) (|v - hi - lo| <= 2^-16 |v|); rows are stored
+//           interleaved per 32 values of k as [hi(32) | lo(32)] (128 B), and the score is
+//           x_hi q_hi + x_hi q_lo + x_lo q_hi (the dropped terms are <= 3 * 2^-16 |x_k q_k| each).
+//           The caller keeps k + margin candidates by this coarse score, re-scores them exactly
+//           (rescore_kernel: the fp32 fma chain of scan_kernel) and proves the margin sufficient
+//           (margin_check_kernel) or falls back to scan_kernel for that query.
+// Structure: the encoder GEMM's persistent ping-pong main loop (gemm_bf16.hip: 8 waves = 2 groups
+// one barrier apart, 256 x 256 tile, K-step of 128 B rows as four 16 KiB half-tiles, LDS-DMA six
+// half-tiles ahead with a counted vmcnt, source-side XOR swizzle, v_mfma_f32_16x16x32_bf16) with
+// the queries on the GEMM's token side (lanes) and the corpus rows on its feature side
+// (accumulator rows), streamed over a strip of corpus tiles, and scan_kernel's epilogue
+// (per-query threshold in LDS, candidate buffers, wave radix compaction).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Scan16Args {
+    const char* X;      // corpus, bf16: [cap_rows][ldk]
+    const char* Q;      // queries, bf16: [nq_pad][ldk]
+    u64* cand;          // [S][nq_pad][CAP]
+    u32* cnt;           // [S][nq_pad]
+    long long n;
+    int ldk;            // row length in bf16 elements: ld (MODE 0) or 2 * ld (MODE 1), multiple of 64
+    int nq, nq_pad, k;
+    int qtiles, strips, total_tiles;
+};
+
+constexpr int S16_HT = 16384, S16_BUF = 4 * S16_HT;
+constexpr int S16_AF = 0, S16_BF = S16_HT, S16_BS = 2 * S16_HT, S16_AS = 3 * S16_HT;
+constexpr int S16_BM = 256, S16_BQ = 256;
+
+template <int MODE, int EPL>
+__global__ __launch_bounds__(512, 2) void scan16_kernel(Scan16Args a) {
+    constexpr int CAP = EPL * 64;
+    static_assert(CAP - S16_BM >= 128, "candidate buffer too small");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32* sCnt = reinterpret_cast<u32*>(smem + 2 * S16_BUF);
+    u32* sThr = sCnt + S16_BQ;
+    u32* sFlag = sThr + S16_BQ;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    int wg;
+    {
+        const int nwg = gridDim.x, per = nwg >> 3, rem = nwg & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        wg = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
+    }
+    const int strip = wg / a.qtiles;           // an XCD's workgroups share corpus strips
+    const int qt = wg - strip * a.qtiles;
+    const int q0 = qt * S16_BQ;
+    const int t0 = (int)(((long long)strip * a.total_tiles) / a.strips);
+    const int t1 = (int)(((long long)(strip + 1) * a.total_tiles) / a.strips);
+    const int KT = a.ldk >> 6;
+    const int total_stages = (t1 - t0) * KT;
+
+    for (int i = tid; i < S16_BQ; i += 512) {
+        sCnt[i] = 0;
+        sThr[i] = (q0 + i < a.nq) ? 0u : 0xFFFFFFFFu;
+    }
+    if (tid == 0) *sFlag = 0;
+    u64* candBase = a.cand + ((size_t)strip * a.nq_pad + q0) * CAP;
+
+    // ---- producer (see gemm_bf16.hip): "A" side = queries, "B" side = corpus rows
+    u32 voffA[2], voffB[2];
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) {
+        const int r = 8 * (wave * 2 + i2) + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int arow = (r & 63) + 128 * (r >> 6);
+        const int wrow = 64 * (r >> 5) + (r & 31);
+        voffA[i2] = ((u32)arow * (u32)a.ldk + (u32)c * 8u) * 2u;
+        voffB[i2] = ((u32)wrow * (u32)a.ldk + (u32)c * 8u) * 2u;
+    }
+    const u32 lds0 = (u32)(uintptr_t)(AS3 char*)smem;
+    const u32 dma_dst = (u32)(wave * 2) * 1024u;
+    const char* gQ = a.Q + (size_t)q0 * a.ldk * 2;
+    int is_stage = 0, is_t = 0, is_tile = t0;
+    bool is_valid = false;
+    const char* is_gA = gQ;
+    const char* is_gW = a.X;
+    u32 is_lds = lds0;
+    auto issue = [&](int kind) -> bool {
+        if (kind == 0) {
+            is_valid = is_stage < total_stages;
+            if (is_valid) {
+                is_gA = gQ + (size_t)is_t * 128;
+                is_gW = a.X + (size_t)is_tile * S16_BM * a.ldk * 2 + (size_t)is_t * 128;
+                is_lds = lds0 + (u32)(is_stage & 1) * S16_BUF + dma_dst;
+                ++is_stage;
+                if (++is_t == KT) { is_t = 0; ++is_tile; }
+            }
+        }
+        if (is_valid) {
+            if (kind == 0) {
+                dma16s(is_gA, voffA[0], is_lds + S16_AF);
+                dma16s(is_gA, voffA[1], is_lds + S16_AF + 1024);
+            } else if (kind == 1) {
+                dma16s(is_gW, voffB[0], is_lds + S16_BF);
+                dma16s(is_gW, voffB[1], is_lds + S16_BF + 1024);
+            } else if (kind == 2) {
+                const char* b = is_gW + (size_t)32 * a.ldk * 2;
+                dma16s(b, voffB[0], is_lds + S16_BS);
+                dma16s(b, voffB[1], is_lds + S16_BS + 1024);
+            } else {
+                const char* b = is_gA + (size_t)64 * a.ldk * 2;
+                dma16s(b, voffA[0], is_lds + S16_AS);
+                dma16s(b, voffA[1], is_lds + S16_AS + 1024);
+            }
+        }
+        return is_valid;
+    };
+    auto stage_and_wait = [&](int kind) {
+        if (issue(kind)) wait_vmcnt<8>();
+        else wait_vmcnt<0>();
+    };
+    auto bar = []() { asm volatile("s_barrier" ::: "memory"); };
+
+    // ---- consumer
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[m][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const u32 xrow = (u32)(64 * g + fr) * 128u;
+    const u32 wrow = (u32)(32 * wn + fr) * 128u;
+    const u32 coff0 = (u32)((fq) ^ (fr >> 1)) << 4;
+    const u32 coff1 = (u32)((4 + fq) ^ (fr >> 1)) << 4;
+    float4 X0[4][2], X1[4][2], Wf[2][2][2];
+    auto ldX = [&](float4 (&X)[4][2], const char* base) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            X[mb][0] = *reinterpret_cast<const float4*>(base + xrow + mb * 2048 + coff0);
+            X[mb][1] = *reinterpret_cast<const float4*>(base + xrow + mb * 2048 + coff1);
+        }
+    };
+    auto ldW = [&](int nq, const char* base) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            Wf[nq][nb][0] = *reinterpret_cast<const float4*>(base + wrow + nb * 2048 + coff0);
+            Wf[nq][nb][1] = *reinterpret_cast<const float4*>(base + wrow + nb * 2048 + coff1);
+        }
+    };
+    auto mfma = [&](f32x4& c, const float4& w, const float4& x) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+    };
+    auto mma = [&](float4 (&X)[4][2], int mq, int nq) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        if (MODE == 0) {
+            // chunk 0 / 1 of the 128-B row = k 0..31 / 32..63 of this K-step
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) mfma(acc[4 * mq + mb][2 * nq + nb], Wf[nq][nb][ks], X[mb][ks]);
+        } else {
+            // chunk 0 / 1 = hi / lo planes of the same 32 values of k: hi hi + hi lo + lo hi
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) mfma(acc[4 * mq + mb][2 * nq + nb], Wf[nq][nb][0], X[mb][0]);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) mfma(acc[4 * mq + mb][2 * nq + nb], Wf[nq][nb][0], X[mb][1]);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) mfma(acc[4 * mq + mb][2 * nq + nb], Wf[nq][nb][1], X[mb][0]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // threshold filter of one finished tile: lane = query (8 of them), 16 corpus rows per query
+    auto epilogue = [&](int tile) {
+        const long long rbase = (long long)tile * S16_BM + 64 * wn + 4 * fq;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int ql = 128 * g + 16 * m + fr;
+            const u32 thr = sThr[ql];
+            const float thrf = key2f(thr);
+            u64* qbuf = candBase + (size_t)ql * CAP;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const f32x4 v = acc[m][nb];
+                const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                if (thr == 0u || mx > thrf || mx != mx) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const long long grow = rbase + 16 * nb + i;
+                        const u32 key = f2key(v[i]);
+                        if (key > thr && grow < a.n) {
+                            const u32 pos = atomicAdd(&sCnt[ql], 1u);
+                            if (pos < (u32)CAP) qbuf[pos] = ((u64)key << 32) | (u64)(0xFFFFFFFFu - (u32)grow);
+                            if (pos + 1 > (u32)(CAP - S16_BM)) *sFlag = 1;
+                        }
+                    }
+                }
+                acc[m][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto compact_pass = [&](bool final_pass) {
+        wait_vmcnt<0>();
+        wg_barrier();
+        for (int q = wave; q < S16_BQ; q += 8) {
+            const int n = (int)sCnt[q];
+            const bool need = final_pass ? (n > a.k) : (n > CAP - S16_BM);
+            if (need) {
+                const u64 T = wave_compact<EPL>(candBase + (size_t)q * CAP, n, a.k, lane);
+                if (lane == 0) {
+                    sCnt[q] = (u32)a.k;
+                    sThr[q] = (u32)(T >> 32);
+                }
+            }
+        }
+        if (tid == 0) *sFlag = 0;
+        wait_vmcnt<0>();
+        wg_barrier();
+    };
+
+    if (total_stages > 0) {
+        issue(0); issue(1); issue(2); issue(3);
+        issue(0);
+        if (issue(1)) wait_vmcnt<8>();
+        else wait_vmcnt<0>();
+    }
+    __syncthreads();
+    if (total_stages > 0) {
+        ldX(X0, smem + S16_AF);
+        if (g == 1) bar();               // group 1 runs one barrier behind
+        int c_t = 0, c_tile = t0;
+        for (int cs = 0; cs < total_stages; ++cs) {
+            const char* lb = smem + (cs & 1) * S16_BUF;
+            ldW(0, lb + S16_BF);
+            stage_and_wait(2);
+            bar();
+            mma(X0, 0, 0);
+            bar();
+            ldW(1, lb + S16_BS);
+            stage_and_wait(3);
+            bar();
+            mma(X0, 0, 1);
+            bar();
+            ldX(X1, lb + S16_AS);
+            stage_and_wait(0);
+            bar();
+            mma(X1, 1, 1);
+            bar();
+            if (cs + 1 < total_stages) ldX(X0, smem + ((cs + 1) & 1) * S16_BUF + S16_AF);
+            stage_and_wait(1);
+            bar();
+            mma(X1, 1, 0);
+            if (++c_t == KT) {
+                c_t = 0;
+                if (g == 1) epilogue(c_tile);
+                wg_barrier();
+                if (g == 0) {
+                    epilogue(c_tile);
+                    wg_barrier();        // group 0 waits for group 1: every wave is past its epilogue
+                }
+                if (__builtin_amdgcn_readfirstlane(*sFlag)) compact_pass(false);   // same barriers for all waves
+                ++c_tile;
+                if (g == 1 && cs + 1 < total_stages) bar();   // fall one barrier behind again
+            } else {
+                bar();
+            }
+        }
+        // after the last tile group 1 did not fall behind again: the groups are level here
+    }
+    compact_pass(true);
+    for (int i = tid; i < S16_BQ; i += 512) a.cnt[(size_t)strip * a.nq_pad + q0 + i] = sCnt[i];
+}
+
+// fp32 rows [rows][d] -> bf16 rows [rows_pad][ld] (MODE 0), zero padded
+__global__ void to_bf16_rows_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long long rows,
+                                    long long rows_pad, int d, int ld) {
+    const long long total = rows_pad * ld;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / ld;
+        const int c = (int)(i - r * ld);
+        const float v = (r < rows && c < d) ? src[r * d + c] : 0.0f;
+        dst[i] = __builtin_bit_cast(unsigned short, (__bf16)v);
+    }
+}
+
+// fp32 rows [rows][sld] (first d valid) -> split rows [rows_pad][2 ld]: per 32 values of k, 32 hi then 32 lo
+// (MODE 1); optionally the squared norm of every row (norm2[rows_pad]) for the error bound.
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, long long sld,
+                                                         unsigned short* __restrict__ dst, long long rows,
+                                                         long long rows_pad, int d, int ld, float* norm2) {
+    const int lane = threadIdx.x & 63;
+    const long long w0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long r = w0; r < rows_pad; r += nw) {      // one wave per row
+        float ss = 0.f;
+        for (int c = lane; c < ld; c += 64) {
+            const float v = (r < rows && c < d) ? src[r * sld + c] : 0.0f;
+            const __bf16 hi = (__bf16)v;
+            const __bf16 lo = (__bf16)(v - (float)hi);
+            unsigned short* o = dst + r * 2 * ld + (c >> 5) * 64 + (c & 31);
+            o[0] = __builtin_bit_cast(unsigned short, hi);
+            o[32] = __builtin_bit_cast(unsigned short, lo);
+            ss += v * v;
+        }
+        if (norm2) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+            if (lane == 0) norm2[r] = ss;
+        }
+    }
+}
+
+// max over rows of norm2 (non-negative floats order like their bit patterns; NaN patterns rank above +inf)
+__global__ void max_norm_kernel(const float* norm2, long long rows, u32* out) {
+    u32 m = 0;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < rows; i += (long long)gridDim.x * blockDim.x)
+        m = max(m, __float_as_uint(norm2[i]) & 0x7FFFFFFFu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (u32)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+// Exact scores of the coarse candidates: one wave per (query, 32 candidates), the fp32 matrix
+// cores fed exactly like scan_kernel (16-byte fragments, k order 0,4,1,5,2,6,3,7 per 8), the
+// query in every column, so every output is bit for bit the score scan_kernel computes.
+// Writes composites (exact key, row) into out[s][q][slot] with s = candidate / k.
+struct RescoreArgs {
+    const float* X;        // [n][ld]
+    const float* Q;        // [nq_pad][ld] (zero padded)
+    const long long* Ic;   // [nq][kc] coarse ids (local row + id_base), -1 = none
+    u64* out;              // [S2][nq_pad][k]
+    u32* out_cnt;          // [S2][nq_pad]
+    long long id_base;
+    int ld, kc, k, nq_pad;
+};
+
+__global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x;
+    const int h = lane >> 5, l31 = lane & 31;
+    const float* qrow = a.Q + (size_t)q * a.ld;
+    for (int c0 = wave * 32; c0 < a.kc; c0 += 128) {
+        const int ci = c0 + l31;
+        const long long id = ci < a.kc ? a.Ic[(size_t)q * a.kc + ci] : -1ll;
+        const long long row = id >= 0 ? id - a.id_base : 0;
+        const float* xrow = a.X + (size_t)row * a.ld;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int j = 0; j < a.ld / 8; ++j) {
+            const float4 af = *reinterpret_cast<const float4*>(xrow + 8 * j + 4 * h);
+            const float4 bf = *reinterpret_cast<const float4*>(qrow + 8 * j + 4 * h);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
+        }
+        // lane (column l31, half h) holds rows (r & 3) + 8 (r >> 2) + 4 h; all columns are equal:
+        // column 0's two lanes publish the 32 scores
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rt = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const long long idr = __shfl(id, rt);                 // candidate rt is held by lane rt (h = 0 half)
+            const int cr = c0 + rt;
+            if (l31 == 0 && cr < a.kc) {
+                const int s = cr / a.k, slot = cr - s * a.k;
+                const u64 comp = idr >= 0 ? (((u64)f2key(acc[r]) << 32) | (u64)(0xFFFFFFFFu - (u32)(idr - a.id_base))) : 0ull;
+                a.out[((size_t)s * a.nq_pad + q) * a.k + slot] = comp;
+            }
+        }
+    }
+    // counts: invalid candidates (id < 0) are the tail of the coarse list
+    if (threadIdx.x == 0) {
+        int valid = 0;
+        for (int i = 0; i < a.kc; ++i) valid += a.Ic[(size_t)q * a.kc + i] >= 0;
+        const int S2 = (a.kc + a.k - 1) / a.k;
+        for (int s = 0; s < S2; ++s) a.out_cnt[(size_t)s * a.nq_pad + q] = (u32)max(0, min(a.k, valid - s * a.k));
+    }
+}
+
+// A query's exact top k is proven complete when its k-th exact score exceeds every score a row
+// OUTSIDE the kc coarse candidates can have: (smallest kept coarse score) + eps,
+// eps = rel * |q| * max |x|.  Otherwise (or on any non-finite value) the query is flagged.
+__global__ void margin_check_kernel(const float* Dexact, const float* Dcoarse, const long long* Icoarse,
+                                    const float* qnorm2, const u32* xnorm2_max, float rel, long long nq, int k, int kc,
+                                    long long n, u32* flags, u32* nflag) {
+    const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    bool ok;
+    if (n <= kc) {
+        ok = true;                                              // every row is a candidate
+    } else {
+        const float tc = Dcoarse[q * kc + kc - 1];             // n > kc: the coarse list is full
+        const float ek = Dexact[q * k + k - 1];
+        const float eps = rel * sqrtf(qnorm2[q]) * sqrtf(__uint_as_float(*xnorm2_max));
+        ok = Icoarse[q * kc + kc - 1] >= 0 && ek > tc + eps;    // false on NaN / inf bounds
+    }
+    flags[q] = ok ? 0u : 1u;
+    if (!ok) atomicAdd(nflag, 1u);
+}
+
 // queries -> zero-padded [nq_pad][ld]
 __global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long long rows,
                                 long long rows_pad, int d, int ld) {
@@ -700,6 +1111,37 @@ int pick_cfg(long long nq, int k, ScanCfg* out) {
     return OTTER_OK;
 }
 
+struct Scan16Cfg {
+    int cap;
+    void (*launch)(const Scan16Args&, int grid, hipStream_t);
+};
+
+template <int MODE, int EPL>
+void launch_scan16(const Scan16Args& a, int grid, hipStream_t st) {
+    auto kern = scan16_kernel<MODE, EPL>;
+    const int lds = 2 * S16_BUF + (2 * S16_BQ + 4) * (int)sizeof(u32);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+}
+
+// largest k the bf16-MFMA scan keeps per query (its compaction holds CAP / 64 composites per lane)
+constexpr int S16_MAX_K = 1024;
+
+template <int MODE>
+int pick_cfg16(int k, Scan16Cfg* out) {
+    if (k <= 128) *out = Scan16Cfg{8 * 64, &launch_scan16<MODE, 8>};
+    else if (k <= 512) *out = Scan16Cfg{20 * 64, &launch_scan16<MODE, 20>};
+    else if (k <= S16_MAX_K) *out = Scan16Cfg{36 * 64, &launch_scan16<MODE, 36>};
+    else return set_err(OTTER_EINVAL, "search: k=%d exceeds %d, the bound of the bf16 scan", k, S16_MAX_K);
+    return OTTER_OK;
+}
+
 int next_pow2(int x) {
     int p = 1;
     while (p < x) p <<= 1;
@@ -711,7 +1153,15 @@ int next_pow2(int x) {
 struct otter_index {
     int d = 0, ld = 0, dtype = OTTER_F32, device = 0, ncu = 256;
     long long n = 0, cap_rows = 0, id_base = 0;
-    float* x = nullptr;
+    float* x = nullptr;             // OTTER_F32: [cap_rows][ld] fp32
+    unsigned short* x16 = nullptr;  // OTTER_BF16: [cap_rows][ld] bf16
+    // OTTER_F32, built on first use by a large query batch: hi/lo bf16 planes [cap_rows][2 ld],
+    // squared row norms and their maximum (bit pattern) for the coarse pass's error bound
+    otter::DevBuf xs, xnorm2, xnmax;
+    long long xs_rows = 0, xs_cap = 0;
+    bool xs_failed = false, no_split = false;
+    long long last_fallback = 0;    // queries of the last split search that went to the exact kernel
+    otter::DevBuf qs, qnorm2, cD, cI, rs, rscnt, flags, fb_q, fb_D, fb_I;
     otter::DevBuf qpad, cand, cnt, lvl[2], lvlcnt[2], smp, smpcnt, thr0, io_q, io_D, io_I;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
@@ -721,29 +1171,33 @@ namespace {
 
 int index_reserve_rows(otter_index* ix, long long need_rows, hipStream_t st) {
     if (need_rows <= ix->cap_rows) return OTTER_OK;
-    // capacity is kept a multiple of the largest scan tile (256 rows): the kernel reads whole tiles
-    // and masks rows >= n, so the tail of the last tile must be addressable
+    // capacity is kept a multiple of the largest scan tile (256 rows): the kernels read whole tiles
+    // and mask rows >= n, so the tail of the last tile must be addressable
+    const size_t esz = ix->dtype == OTTER_BF16 ? 2 : 4;
+    void* old = ix->dtype == OTTER_BF16 ? (void*)ix->x16 : (void*)ix->x;
     need_rows = round_up64(need_rows, 256);
     long long want = ix->cap_rows == 0 ? need_rows : std::max(need_rows, ix->cap_rows + ix->cap_rows / 2);
     want = round_up64(want, 256);
-    float* nx = nullptr;
-    hipError_t e = hipMalloc((void**)&nx, (size_t)want * ix->ld * sizeof(float));
+    void* nx = nullptr;
+    hipError_t e = hipMalloc(&nx, (size_t)want * ix->ld * esz);
     if (e != hipSuccess && want > need_rows) {
         (void)hipGetLastError();
         want = need_rows;
-        e = hipMalloc((void**)&nx, (size_t)want * ix->ld * sizeof(float));
+        e = hipMalloc(&nx, (size_t)want * ix->ld * esz);
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        return set_err(OTTER_ENOMEM, "add: hipMalloc of %lld rows x %d floats failed: %s", want, ix->ld,
+        return set_err(OTTER_ENOMEM, "add: hipMalloc of %lld rows x %d x %zu bytes failed: %s", want, ix->ld, esz,
                        hipGetErrorString(e));
     }
-    if (ix->n > 0) {
-        OTTER_HIP_TRY(hipMemcpyAsync(nx, ix->x, (size_t)ix->n * ix->ld * sizeof(float), hipMemcpyDeviceToDevice, st));
-        OTTER_HIP_TRY(hipStreamSynchronize(st));
-    }
-    if (ix->x) OTTER_HIP_TRY(hipFree(ix->x));
-    ix->x = nx;
+    // rows past n are read by whole-tile loads (and multiplied by real queries): keep them finite
+    OTTER_HIP_TRY(hipMemsetAsync(nx, 0, (size_t)want * ix->ld * esz, st));
+    if (ix->n > 0)
+        OTTER_HIP_TRY(hipMemcpyAsync(nx, old, (size_t)ix->n * ix->ld * esz, hipMemcpyDeviceToDevice, st));
+    OTTER_HIP_TRY(hipStreamSynchronize(st));
+    if (old) OTTER_HIP_TRY(hipFree(old));
+    if (ix->dtype == OTTER_BF16) ix->x16 = (unsigned short*)nx;
+    else ix->x = (float*)nx;
     ix->cap_rows = want;
     return OTTER_OK;
 }
@@ -811,8 +1265,24 @@ int run_merge(otter_index* ix, const u64* in, const u32* in_cnt, int cap_in, int
     return OTTER_OK;
 }
 
+int search_chunk_bf16(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st);
+int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, int kc, float* D, long long* I,
+                       hipStream_t st);
+int ensure_split_planes(otter_index* ix, hipStream_t st);
+
 // one scan + merge over queries [qd, qd + nq) (device pointers), results to device D/I
 int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st) {
+    if (ix->dtype == OTTER_BF16) return search_chunk_bf16(ix, qd, nq, k, D, I, st);
+    {
+        // MFMA-bound batches on a large corpus: coarse pass on the bf16 matrix cores + exact re-scoring
+        static const char* no_split_env = getenv("OTTER_NO_SPLIT");
+        const int kc = k + std::max(28, k / 8);
+        if (!no_split_env && !ix->no_split && nq >= 192 && ix->n >= 65536 && kc <= S16_MAX_K) {
+            const int rs = ensure_split_planes(ix, st);
+            if (rs < 0) return rs;
+            if (rs == 0) return search_chunk_split(ix, qd, nq, k, kc, D, I, st);
+        }
+    }
     ScanCfg cfg;
     int rc = pick_cfg(nq, k, &cfg);
     if (rc) return rc;
@@ -929,6 +1399,198 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
                      nullptr, nullptr, st);
 }
 
+int launch_scan16_timed(otter_index* ix, const Scan16Cfg& cfg, const Scan16Args& sa, int grid, hipStream_t st) {
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    const bool timed = ix->timing && ix->ev_pending.size() < 4096;
+    if (timed) {
+        if (!ix->ev_free.empty()) {
+            ev = ix->ev_free.back();
+            ix->ev_free.pop_back();
+        } else {
+            OTTER_HIP_TRY(hipEventCreate(&ev.first));
+            OTTER_HIP_TRY(hipEventCreate(&ev.second));
+        }
+        OTTER_HIP_TRY(hipEventRecord(ev.first, st));
+    }
+    cfg.launch(sa, grid, st);
+    OTTER_HIP_TRY(hipGetLastError());
+    if (timed) {
+        OTTER_HIP_TRY(hipEventRecord(ev.second, st));
+        ix->ev_pending.push_back(ev);
+    }
+    return OTTER_OK;
+}
+
+// common part of the two bf16-MFMA searches: scan `Xk` (bf16 rows of ldk elements) for the queries
+// in ix->qs and merge to (Dc, Ic) [nq, kk]
+template <int MODE>
+int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int kk, float* Dc, long long* Ic,
+                     hipStream_t st) {
+    Scan16Cfg cfg;
+    int rc = pick_cfg16<MODE>(kk, &cfg);
+    if (rc) return rc;
+    const long long nq_pad = round_up64(nq, S16_BQ);
+    const int qtiles = (int)(nq_pad / S16_BQ);
+    const int total_tiles = (int)((ix->n + S16_BM - 1) / S16_BM);
+    int strips = std::min(std::max(1, ix->ncu / qtiles), total_tiles);
+    if ((rc = ix->cand.reserve((size_t)strips * nq_pad * cfg.cap * sizeof(u64)))) return rc;
+    if ((rc = ix->cnt.reserve((size_t)strips * nq_pad * sizeof(u32)))) return rc;
+    Scan16Args sa;
+    sa.X = (const char*)Xk;
+    sa.Q = (const char*)ix->qs.p;
+    sa.cand = (u64*)ix->cand.p;
+    sa.cnt = (u32*)ix->cnt.p;
+    sa.n = ix->n;
+    sa.ldk = ldk;
+    sa.nq = (int)nq;
+    sa.nq_pad = (int)nq_pad;
+    sa.k = kk;
+    sa.qtiles = qtiles;
+    sa.strips = strips;
+    sa.total_tiles = total_tiles;
+    if ((rc = launch_scan16_timed(ix, cfg, sa, qtiles * strips, st))) return rc;
+    return run_merge(ix, (const u64*)ix->cand.p, (const u32*)ix->cnt.p, cfg.cap, strips, nq, nq_pad, kk, true, Dc, Ic,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, st);
+}
+
+// OTTER_BF16 index: queries rounded to bf16, scores accumulated in fp32
+int search_chunk_bf16(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st) {
+    const long long nq_pad = round_up64(nq, S16_BQ);
+    int rc;
+    if ((rc = ix->qs.reserve((size_t)nq_pad * ix->ld * 2))) return rc;
+    {
+        const long long total = nq_pad * ix->ld;
+        hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256),
+                           0, st, qd, (unsigned short*)ix->qs.p, nq, nq_pad, ix->d, ix->ld);
+        OTTER_HIP_TRY(hipGetLastError());
+    }
+    return scan16_and_merge<0>(ix, ix->x16, ix->ld, nq, k, D, I, st);
+}
+
+// relative error bound of the coarse score against scan_kernel's fp32 chain, as a multiple of
+// |q| |x|: dropped split terms 3 * 2^-16 = 4.6e-5, fp32 accumulation of 3 d / 32 MFMA partial sums
+// and of the d-term fma chain it is compared with (each <= d * 2^-24 = 4.6e-5 at d = 768, growing
+// with d): 2e-4 covers d <= 1024 with margin; larger d scales it
+float split_rel_eps(int d) { return 2e-4f * std::max(1.0f, (float)d / 1024.0f); }
+
+int ensure_split_planes(otter_index* ix, hipStream_t st) {
+    if (ix->xs_failed) return 1;
+    if (ix->xs_cap < ix->cap_rows) {
+        ix->xs.release();
+        ix->xnorm2.release();
+        ix->xs_rows = 0;
+        ix->xs_cap = 0;
+        hipError_t e = hipMalloc(&ix->xs.p, (size_t)ix->cap_rows * ix->ld * 4);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            ix->xs.p = nullptr;
+            ix->xs_failed = true;           // not enough HBM for the planes: the exact kernel serves every batch
+            return 1;
+        }
+        ix->xs.bytes = (size_t)ix->cap_rows * ix->ld * 4;
+        OTTER_HIP_TRY(hipMemsetAsync(ix->xs.p, 0, ix->xs.bytes, st));
+        int rc;
+        if ((rc = ix->xnorm2.reserve((size_t)ix->cap_rows * sizeof(float)))) return rc;
+        if ((rc = ix->xnmax.reserve(sizeof(u32)))) return rc;
+        OTTER_HIP_TRY(hipMemsetAsync(ix->xnmax.p, 0, sizeof(u32), st));
+        ix->xs_cap = ix->cap_rows;
+    }
+    if (ix->xs_rows < ix->n) {
+        const long long lo = ix->xs_rows, rows = ix->n - lo;
+        hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)std::min<long long>((rows + 3) / 4, 16384)), dim3(256), 0,
+                           st, ix->x + (size_t)lo * ix->ld, (long long)ix->ld,
+                           (unsigned short*)ix->xs.p + (size_t)lo * 2 * ix->ld, rows, rows, ix->ld, ix->ld,
+                           (float*)ix->xnorm2.p + lo);
+        hipLaunchKernelGGL(max_norm_kernel, dim3((unsigned)std::min<long long>((rows + 255) / 256, 1024)), dim3(256), 0,
+                           st, (const float*)ix->xnorm2.p + lo, rows, (u32*)ix->xnmax.p);
+        OTTER_HIP_TRY(hipGetLastError());
+        ix->xs_rows = ix->n;
+    }
+    return OTTER_OK;
+}
+
+int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st);
+
+// Exact fp32 search of a large query batch through the bf16 matrix cores: coarse top-(k + margin)
+// on hi/lo bf16 planes, exact re-scoring of those candidates with scan_kernel's fp32 chain, a
+// per-query proof that no other row can reach the top k, and scan_kernel itself for the (rare)
+// queries without a proof.  Results are identical to search_chunk's.
+int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, int kc, float* D, long long* I,
+                       hipStream_t st) {
+    const long long nq_pad = round_up64(nq, S16_BQ);
+    const int S2 = (kc + k - 1) / k;
+    int rc;
+    if ((rc = ix->qs.reserve((size_t)nq_pad * ix->ld * 4))) return rc;
+    if ((rc = ix->qnorm2.reserve((size_t)nq_pad * sizeof(float)))) return rc;
+    if ((rc = ix->qpad.reserve((size_t)nq_pad * ix->ld * sizeof(float)))) return rc;
+    if ((rc = ix->cD.reserve((size_t)nq * kc * sizeof(float)))) return rc;
+    if ((rc = ix->cI.reserve((size_t)nq * kc * sizeof(long long)))) return rc;
+    if ((rc = ix->rs.reserve((size_t)S2 * nq_pad * k * sizeof(u64)))) return rc;
+    if ((rc = ix->rscnt.reserve((size_t)S2 * nq_pad * sizeof(u32)))) return rc;
+    if ((rc = ix->flags.reserve((size_t)(nq + 1) * sizeof(u32)))) return rc;
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)std::min<long long>((nq_pad + 3) / 4, 16384)), dim3(256), 0, st,
+                       qd, (long long)ix->d, (unsigned short*)ix->qs.p, nq, nq_pad, ix->d, ix->ld, (float*)ix->qnorm2.p);
+    {
+        const long long total = nq_pad * ix->ld;
+        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0,
+                           st, qd, (float*)ix->qpad.p, nq, nq_pad, ix->d, ix->ld);
+    }
+    OTTER_HIP_TRY(hipGetLastError());
+    if ((rc = scan16_and_merge<1>(ix, ix->xs.p, 2 * ix->ld, nq, kc, (float*)ix->cD.p, (long long*)ix->cI.p, st)))
+        return rc;
+    RescoreArgs ra;
+    ra.X = ix->x;
+    ra.Q = (const float*)ix->qpad.p;
+    ra.Ic = (const long long*)ix->cI.p;
+    ra.out = (u64*)ix->rs.p;
+    ra.out_cnt = (u32*)ix->rscnt.p;
+    ra.id_base = ix->id_base;
+    ra.ld = ix->ld;
+    ra.kc = kc;
+    ra.k = k;
+    ra.nq_pad = (int)nq_pad;
+    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq), dim3(256), 0, st, ra);
+    OTTER_HIP_TRY(hipGetLastError());
+    if ((rc = run_merge(ix, (const u64*)ix->rs.p, (const u32*)ix->rscnt.p, k, S2, nq, nq_pad, k, true, D, I, nullptr,
+                        nullptr, nullptr, nullptr, nullptr, st)))
+        return rc;
+    u32* flags = (u32*)ix->flags.p;
+    OTTER_HIP_TRY(hipMemsetAsync(flags + nq, 0, sizeof(u32), st));
+    hipLaunchKernelGGL(margin_check_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (const float*)D,
+                       (const float*)ix->cD.p, (const long long*)ix->cI.p, (const float*)ix->qnorm2.p,
+                       (const u32*)ix->xnmax.p, split_rel_eps(ix->d), nq, k, kc, ix->n, flags, flags + nq);
+    OTTER_HIP_TRY(hipGetLastError());
+    // the one host round trip of this path: how many queries are left without a proof
+    std::vector<u32> hflags((size_t)nq + 1);
+    OTTER_HIP_TRY(hipMemcpyAsync(hflags.data(), flags, (size_t)(nq + 1) * sizeof(u32), hipMemcpyDeviceToHost, st));
+    OTTER_HIP_TRY(hipStreamSynchronize(st));
+    const long long nf = hflags[(size_t)nq];
+    ix->last_fallback = nf;
+    if (nf == 0) return OTTER_OK;
+    // unproven queries: gather them, run the exact kernel, scatter the rows back
+    if ((rc = ix->fb_q.reserve((size_t)nf * ix->d * sizeof(float)))) return rc;
+    if ((rc = ix->fb_D.reserve((size_t)nf * k * sizeof(float)))) return rc;
+    if ((rc = ix->fb_I.reserve((size_t)nf * k * sizeof(long long)))) return rc;
+    std::vector<long long> which;
+    for (long long q = 0; q < nq; ++q)
+        if (hflags[(size_t)q]) which.push_back(q);
+    for (size_t i = 0; i < which.size(); ++i)
+        OTTER_HIP_TRY(hipMemcpyAsync((float*)ix->fb_q.p + i * ix->d, qd + (size_t)which[i] * ix->d,
+                                     (size_t)ix->d * sizeof(float), hipMemcpyDeviceToDevice, st));
+    ix->no_split = true;
+    rc = search_chunk(ix, (const float*)ix->fb_q.p, (long long)which.size(), k, (float*)ix->fb_D.p,
+                      (long long*)ix->fb_I.p, st);
+    ix->no_split = false;
+    if (rc) return rc;
+    for (size_t i = 0; i < which.size(); ++i) {
+        OTTER_HIP_TRY(hipMemcpyAsync(D + (size_t)which[i] * k, (float*)ix->fb_D.p + i * k, (size_t)k * sizeof(float),
+                                     hipMemcpyDeviceToDevice, st));
+        OTTER_HIP_TRY(hipMemcpyAsync(I + (size_t)which[i] * k, (long long*)ix->fb_I.p + i * k,
+                                     (size_t)k * sizeof(long long), hipMemcpyDeviceToDevice, st));
+    }
+    return OTTER_OK;
+}
+
 // n == 0: every result is padding
 __global__ void fill_empty_kernel(float* D, long long* I, long long total) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -946,8 +1608,8 @@ int otter_index_create(int d, int dtype, int device, otter_index** out) {
     if (!out) return set_err(OTTER_EINVAL, "index_create: out is NULL");
     *out = nullptr;
     if (d <= 0 || d > (1 << 20)) return set_err(OTTER_EINVAL, "index_create: bad dimension d=%d", d);
-    if (dtype != OTTER_F32)
-        return set_err(OTTER_ENOTIMPL, "index_create: only OTTER_F32 corpus storage is built (dtype=%d)", dtype);
+    if (dtype != OTTER_F32 && dtype != OTTER_BF16)
+        return set_err(OTTER_ENOTIMPL, "index_create: corpus storage is OTTER_F32 or OTTER_BF16 (dtype=%d)", dtype);
     int ndev = 0;
     OTTER_HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev)
@@ -981,6 +1643,26 @@ int otter_index_add(otter_index* ix, const void* x, int64_t n, int x_is_device, 
     hipStream_t st = (hipStream_t)stream;
     int rc = index_reserve_rows(ix, ix->n + n, st);
     if (rc) return rc;
+    if (ix->dtype == OTTER_BF16) {
+        // rows arrive as float32 (the reference's .npy) and are rounded to bf16 on the device, slab by slab
+        const long long slab = 65536;
+        for (long long lo = 0; lo < n; lo += slab) {
+            const long long c = std::min<long long>(slab, n - lo);
+            const float* src = (const float*)x + (size_t)lo * ix->d;
+            if (!x_is_device) {
+                if ((rc = ix->io_q.reserve((size_t)c * ix->d * sizeof(float)))) return rc;
+                OTTER_HIP_TRY(hipMemcpyAsync(ix->io_q.p, src, (size_t)c * ix->d * sizeof(float), hipMemcpyHostToDevice, st));
+                src = (const float*)ix->io_q.p;
+            }
+            const long long total = c * ix->ld;
+            hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 8192)),
+                               dim3(256), 0, st, src, ix->x16 + (size_t)(ix->n + lo) * ix->ld, c, c, ix->d, ix->ld);
+            OTTER_HIP_TRY(hipGetLastError());
+            if (!x_is_device) OTTER_HIP_TRY(hipStreamSynchronize(st));   // the staging slab is reused
+        }
+        ix->n += n;
+        return OTTER_OK;
+    }
     float* dst = ix->x + (size_t)ix->n * ix->ld;
     const hipMemcpyKind kind = x_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     if (ix->ld == ix->d) {
@@ -1047,6 +1729,11 @@ int otter_index_d(const otter_index* ix) { return ix ? ix->d : -1; }
 int otter_index_reset(otter_index* ix) {
     if (!ix) return set_err(OTTER_EINVAL, "reset: index is NULL");
     ix->n = 0;
+    ix->xs_rows = 0;
+    if (ix->xnmax.p) {
+        DeviceGuard g(ix->device);
+        OTTER_HIP_TRY(hipMemset(ix->xnmax.p, 0, sizeof(u32)));
+    }
     return OTTER_OK;
 }
 
@@ -1080,12 +1767,18 @@ int otter_index_timing(otter_index* ix, double* scan_ms, int64_t* scan_launches)
     return OTTER_OK;
 }
 
+int64_t otter_index_last_fallback(const otter_index* ix) { return ix ? ix->last_fallback : -1; }
+
 void otter_index_destroy(otter_index* ix) {
     if (!ix) return;
     DeviceGuard g(ix->device);
     for (auto& ev : ix->ev_pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : ix->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ix->x) (void)hipFree(ix->x);
+    if (ix->x16) (void)hipFree(ix->x16);
+    for (otter::DevBuf* b : {&ix->xs, &ix->xnorm2, &ix->xnmax, &ix->qs, &ix->qnorm2, &ix->cD, &ix->cI, &ix->rs,
+                             &ix->rscnt, &ix->flags, &ix->fb_q, &ix->fb_D, &ix->fb_I})
+        b->release();
     ix->qpad.release();
     ix->cand.release();
     ix->cnt.release();

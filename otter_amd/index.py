@@ -38,15 +38,19 @@ class IndexFlatIP:
     d : int            vector dimension (768, or 768*3 for the reference's three-cat embeddings)
     device : int       HIP device ordinal
     id_base : int      added to every reported id (row-sharded use: the shard's first global row)
+    dtype : str        'fp32' = IndexFlatIP's arithmetic; 'bf16' = rows and queries rounded to bfloat16
     """
 
-    def __init__(self, d, device=0, id_base=0):
+    def __init__(self, d, device=0, id_base=0, dtype="fp32"):
         self._lib = _lib.load()
         self.d = int(d)
         self.device = int(device)
+        if dtype not in ("fp32", "bf16"):
+            raise ValueError("dtype must be 'fp32' (IndexFlatIP arithmetic) or 'bf16' (storage of the 100M-row config)")
+        self.dtype = dtype
         self._h = ctypes.c_void_p()
-        _lib.check(self._lib.otter_index_create(self.d, _lib.OTTER_F32, self.device, ctypes.byref(self._h)),
-                   "otter_index_create")
+        _lib.check(self._lib.otter_index_create(self.d, _lib.OTTER_BF16 if dtype == "bf16" else _lib.OTTER_F32,
+                                                self.device, ctypes.byref(self._h)), "otter_index_create")
         self.id_base = 0
         if id_base:
             self.set_id_base(id_base)
@@ -115,6 +119,11 @@ class IndexFlatIP:
                                                 ctypes.c_void_p(D.ctypes.data), ctypes.c_void_p(I.ctypes.data), 0,
                                                 _stream_ptr(self.device)), "otter_index_search")
         return D, I
+
+    @property
+    def last_fallback(self):
+        """Queries of the last search() that the coarse bf16 pass could not prove and the exact kernel re-did."""
+        return int(self._lib.otter_index_last_fallback(self._h))
 
     def reset(self):
         _lib.check(self._lib.otter_index_reset(self._h), "otter_index_reset")

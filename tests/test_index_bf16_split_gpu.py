@@ -1,0 +1,117 @@
+"""GPU parity of the two bf16-matrix-core search paths (otter_amd/csrc/index.hip: scan16_kernel).
+
+* OTTER_F32 index, large query batch ("split" path): coarse pass on hi/lo bf16 planes + exact
+  re-scoring + per-query proof, exact kernel for unproven queries.  The result must be what the exact
+  kernel returns: D and I BIT-EXACT against oracle mode 1 (oracle/flat_ip.c), ties included.
+* OTTER_BF16 index (BASELINE config 5 storage): rows and queries rounded to bfloat16, fp32
+  accumulation.  Reported separately from fp32 parity, as north_star says: checked with the order-free
+  rule of SURVEY.md §8c against float64 scores of the ROUNDED operands, plus recall@k against the
+  fp32 index of the unrounded data.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import flat_ip
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(n, d, nq, seed):
+    rng = np.random.RandomState(seed)
+    return rng.randn(n, d).astype(np.float32), rng.randn(nq, d).astype(np.float32)
+
+
+def _bf16_round(a):
+    return torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def _search(xb, q, k, dtype="fp32"):
+    from otter_amd.index import IndexFlatIP
+    ix = IndexFlatIP(xb.shape[1], dtype=dtype)
+    ix.add(xb)
+    D, I = ix.search(q, k)
+    fb = ix.last_fallback
+    ix.close()
+    return D, I, fb
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(70000, 768, 200, 100), (66000, 128, 700, 10), (131072, 768, 256, 1),
+                                        (80000, 64, 300, 500), (70001, 2304, 193, 100)])
+def test_split_path_is_bit_exact(n, d, nq, k):
+    xb, q = _mk(n, d, nq, seed=n + d + nq + k)
+    D, I, fb = _search(xb, q, k)
+    Dr, Ir = flat_ip.search_c(xb, q, k, mode=flat_ip.MODE_GPU_ORDER)
+    np.testing.assert_array_equal(I, Ir)
+    np.testing.assert_array_equal(D.view(np.uint32), Dr.view(np.uint32))
+    assert fb <= nq // 20, "gaussian data should almost never need the exact fallback (%d of %d)" % (fb, nq)
+
+
+def test_split_path_falls_back_on_near_ties_and_stays_exact():
+    # 70,000 rows that are tiny perturbations of 40 prototypes: hundreds of rows per query sit inside the
+    # coarse pass's error bound of the k-th score, so the proof fails and the exact kernel must take over
+    rng = np.random.RandomState(3)
+    n, d, nq, k = 70000, 256, 200, 100
+    proto = rng.randn(40, d).astype(np.float32)
+    xb = proto[rng.randint(0, 40, size=n)] * (1.0 + 1e-6 * rng.randn(n, 1).astype(np.float32))
+    xb = xb.astype(np.float32)
+    xb[1000:1100] = xb[7]                                   # exact duplicates too: (score desc, id asc)
+    q = rng.randn(nq, d).astype(np.float32)
+    D, I, fb = _search(xb, q, k)
+    Dr, Ir = flat_ip.search_c(xb, q, k, mode=flat_ip.MODE_GPU_ORDER)
+    np.testing.assert_array_equal(I, Ir)
+    np.testing.assert_array_equal(D.view(np.uint32), Dr.view(np.uint32))
+    assert fb > 0, "this corpus is built to defeat the margin proof"
+
+
+def test_split_path_non_finite_rows_and_incremental_add():
+    from otter_amd.index import IndexFlatIP
+    xb, q = _mk(90000, 128, 220, seed=21)
+    q = np.abs(q)
+    xb[5] = np.inf
+    xb[77777] = -np.inf
+    ix = IndexFlatIP(128)
+    ix.add(xb[:30000])
+    D0, I0 = ix.search(q, 20)                               # n < 65536: exact kernel
+    ix.add(xb[30000:])                                      # planes are built / extended on the next large batch
+    D, I = ix.search(q, 20)
+    assert ix.last_fallback == q.shape[0]                   # an infinite norm bound proves nothing: all exact
+    ix.close()
+    Dr, Ir = flat_ip.search_c(xb, q, 20, mode=flat_ip.MODE_GPU_ORDER)
+    np.testing.assert_array_equal(I, Ir)
+    assert (I[:, 0] == 5).all() and np.isposinf(D[:, 0]).all()
+    np.testing.assert_array_equal(I0, flat_ip.search_c(xb[:30000], q, 20, mode=flat_ip.MODE_GPU_ORDER)[1])
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(5000, 768, 7, 100), (70000, 768, 300, 100), (66000, 100, 33, 1000),
+                                        (300, 64, 5, 400), (100000, 768, 1, 10)])
+def test_bf16_index_against_rounded_operands(n, d, nq, k):
+    xb, q = _mk(n, d, nq, seed=n + d + nq + k + 1)
+    D, I, _ = _search(xb, q, k, dtype="bf16")
+    assert D.dtype == np.float32 and I.dtype == np.int64
+    xr, qr = _bf16_round(xb), _bf16_round(q)
+    # scores are exact products of bf16 values accumulated in fp32 (any order): 1e-5 |q| max|x| covers it
+    flat_ip.check_topk(xr, qr, D, I, k, rtol=1e-5)
+    # recall@k against the fp32 ranking of the unrounded data (reported, with a loose floor)
+    _, Ir = flat_ip.search_c(xb, q, min(k, n), mode=flat_ip.MODE_GPU_ORDER)
+    kk = min(k, n)
+    rec = np.mean([len(set(I[i, :kk]) & set(Ir[i])) / kk for i in range(nq)])
+    assert rec >= 0.9, rec
+
+
+def test_bf16_index_incremental_device_add_and_limits():
+    from otter_amd.index import IndexFlatIP
+    xb, q = _mk(20000, 768, 16, seed=2)
+    ix = IndexFlatIP(768, dtype="bf16", id_base=1 << 35)
+    ix.add(xb[:7000])
+    ix.add(torch.from_numpy(xb[7000:]).cuda())
+    assert ix.ntotal == 20000
+    D, I = ix.search(torch.from_numpy(q).cuda(), 50)
+    flat_ip.check_topk(_bf16_round(xb), _bf16_round(q), D.cpu().numpy(), I.cpu().numpy(), 50, rtol=1e-5,
+                       id_base=1 << 35)
+    with pytest.raises(ValueError):
+        ix.search(q, 2000)                                  # the bf16 scan keeps at most 1024 per query
+    ix.reset()
+    D, I = ix.search(q, 5)
+    assert (I == -1).all()
+    ix.close()

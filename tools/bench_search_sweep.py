@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="fp32", help="corpus storage: fp32 (IndexFlatIP arithmetic) or bf16")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
@@ -37,7 +38,7 @@ def main():
     for lo in range(0, a.rows, 131072):
         hi = min(a.rows, lo + 131072)
         xb[lo:hi] = torch.randn((hi - lo, a.dim), generator=g, device=dev)
-    ix = IndexFlatIP(a.dim, device=0)
+    ix = IndexFlatIP(a.dim, device=0, dtype=a.dtype)
     ix.add(xb)
     del xb
     torch.cuda.empty_cache()
@@ -59,11 +60,12 @@ def main():
         ms, n = ix.timing()
         ix.set_timing(False)
         kms = ms / max(n, 1)
-        gbs = a.rows * a.dim * 4 / (kms * 1e-3) / 1e9
+        gbs = a.rows * a.dim * (2 if a.dtype == 'bf16' else 4) / (kms * 1e-3) / 1e9
         tf = 2.0 * a.rows * a.dim * nq / (kms * 1e-3) / 1e12
         print(json.dumps({"nq": nq, "k": a.k, "rows": a.rows, "scan_ms": round(kms, 4), "wall_ms": round(wall, 4),
                           "GBps": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM, 4), "TFLOPs": round(tf, 2),
-                          "mfma_frac": round(tf / PEAK_F32, 4), "queries_per_s": round(nq / (wall * 1e-3), 1)}),
+                          "mfma_frac": round(tf / PEAK_F32, 4), "queries_per_s": round(nq / (wall * 1e-3), 1),
+                          "dtype": a.dtype, "fallback_queries": ix.last_fallback}),
               flush=True)
     ix.close()
 
