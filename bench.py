@@ -13,8 +13,11 @@ lists are exchanged with one RCCL all-gather and merged on the GPU; `value` coun
 plain queries/s on configs[1].
 
 One JSON line on stdout (rank 0).  `roofline` is for the scan kernel (fp32 MFMA bound at
-nq = 2214): algorithmic flops 2*N*d*nq per launch / HIP-event time of the kernel, taken
-inside the timed region by the library's timing hook on the launch stream.
+nq = 2214).  Large batches run the coarse pass of the exact search on the bf16 matrix cores
+(every fp32 operand split into bf16 hi + lo, three MFMA products per term), so the kernel's work
+per launch is 3 * 2*N*d*nq bf16 flops against the dense bf16 MFMA peak; the fp32-equivalent rate
+2*N*d*nq / t is printed beside it.  Time = HIP events around the kernel, taken inside the timed
+region by the library's timing hook on the launch stream.
 `cpu_baseline` is oracle/flat_ip.py (numpy sgemm + k-select port of IndexFlatIP) timed on
 this box's host cores on a bounded row sample (rank 0, N = 1 only).
 """
@@ -32,6 +35,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: Peak BF16 MFMA, dense
 
 
 def gen_rows(n, d, seed, device, chunk=131072):
@@ -74,7 +78,6 @@ def cpu_baseline(xb_sample_fn, q, k, rows_full, budget_s=15.0):
                       "%.1f s, scaled by rows" % (nq, rows, rows_full, dt)}
 
 
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: Peak BF16 MFMA, dense
 
 
 def encode_leg(rank, world, local_rank, dist, steps, warmup, batch, cpu_ref):
@@ -171,9 +174,10 @@ def main():
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per scan launch from a separate rocprofv3 --pmc pass (profiles/)")
     args = ap.parse_args()
-    if args.traffic_bytes is None and (args.rows, args.dim, args.nq, args.k) == (1000000, 768, 2214, 100):
+    if (args.traffic_bytes is None and (args.rows, args.dim, args.nq, args.k) == (1000000, 768, 2214, 100)
+            and not os.environ.get("OTTER_NO_SPLIT")):
         # HBM-side bytes per scan launch from this round's separate rocprofv3 --pmc passes (profiles/)
-        tp = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        tp = os.path.join(ROOT, "profiles", "r01_traffic_split.json")
         if os.path.exists(tp):
             with open(tp) as f:
                 args.traffic_bytes = float(json.load(f)["scan_kernel_hbm_bytes_per_launch"])
@@ -240,8 +244,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # sanity (outside the timed region): the first 65,536 rows re-scored with torch for 8 queries
+    # sanity (outside the timed region): (1) the timed batch's first 64 rows of (D, I) must equal, bit for bit,
+    # what the exact fp32 kernel returns for those queries alone (a 64-query call never takes the coarse path);
+    # (2) the first 65,536 rows re-scored with torch in float64 for 8 queries
     ok = True
+    fallback = index.last_fallback
+    if rank == 0 and world == 1:
+        De, Ie = index.search(q[:64].contiguous(), k)
+        ok = bool(torch.equal(Ie, I[:64])) and bool(torch.equal(De.view(torch.int32), D[:64].view(torch.int32)))
     if rank == 0:
         small = IndexFlatIP(d, device=local_rank)
         small.add(check_rows)
@@ -249,7 +259,7 @@ def main():
         ref = (q[:8].double() @ check_rows.double().T)
         rs, ri = torch.topk(ref, k, dim=1)
         got = torch.gather(ref, 1, Is)
-        ok = bool((got >= rs[:, -1:] - 1e-3).all().item()) and bool(((Ds.double() - got).abs() < 1e-2).all().item())
+        ok = ok and bool((got >= rs[:, -1:] - 1e-3).all().item()) and bool(((Ds.double() - got).abs() < 1e-2).all().item())
         small.close()
 
     index.close()
@@ -265,7 +275,15 @@ def main():
         value = world * nq * args.steps / elapsed
         kern_ms = scan_ms / max(launches, 1)
         flops = 2.0 * n * d * nq
-        achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+        split = nq >= 192 and n >= 65536 and not os.environ.get("OTTER_NO_SPLIT")
+        if split:   # coarse pass on bf16 hi/lo planes: 3 MFMA products per term
+            kernel_flops, peak = 3.0 * flops, PEAK_BF16_MFMA_TFLOPS
+            kname = ("scan16_kernel<1,8> (256x256 tile, v_mfma_f32_16x16x32_bf16 on hi/lo bf16 planes of the fp32 "
+                     "operands: hi*hi + hi*lo + lo*hi, fused top-k filter; then exact fp32 re-scoring + margin proof)")
+        else:
+            kernel_flops, peak = flops, PEAK_FP32_MFMA_TFLOPS
+            kname = "scan_kernel<4,2,2,2,32,3,8> (256x128 tile, fp32 v_mfma_f32_32x32x2_f32 + fused top-k filter)"
+        achieved = kernel_flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
         out = {
             "metric": "exact top-100 MIPS queries/s over 768-d corpus; corpus encode blocks/s",
             "value": value,
@@ -277,17 +295,23 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16x3 split of f32 operands, f32 accumulate, exact f32 re-scoring (results = f32 IndexFlatIP)"
+                     if split else "f32",
             "data": "synthetic",
             "config": {"workload": "configs[1]: exact top-%d IP search, %d-query batch over %dx%d fp32 corpus "
                                    "per GPU (row-sharded at N>1, RCCL all-gather + GPU merge)" % (k, nq, n, d),
                        "rows_per_gpu": n, "dim": d, "nq": nq, "k": k,
                        "value_counts": "1M-row query scans per second over all ranks (= queries/s at N=1)"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak,
                          "traffic": args.traffic_bytes,
-                         "kernel": "scan_kernel<4,2,2,2,32,3,8> (256x128 tile, fp32 v_mfma_f32_32x32x2_f32 + fused top-k filter)",
+                         "kernel": kname,
                          "kernel_ms": kern_ms, "launches": int(launches),
+                         "kernel_flops_per_launch": kernel_flops,
+                         "f32_equivalent_tflops": flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0,
+                         "f32_equivalent_vs_f32_matrix_peak": (flops / (kern_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS)
+                         if kern_ms > 0 else 0.0,
+                         "exact_fallback_queries_last_step": int(fallback),
                          "algorithmic_flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": float(n) * d * 4 + nq * d * 4 + nq * k * 12,
                          "hbm_frac_if_bandwidth_bound": (float(n) * d * 4 / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS)
