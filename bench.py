@@ -144,11 +144,11 @@ def encode_leg(rank, world, local_rank, dist, steps, warmup, batch, cpu_ref):
     if cpu_ref:
         # fp32 recall-style check of the bf16 path on 2 blocks + CPU baseline timing (oracle restatement)
         ref = R.EncoderRef(cfg, sd)
-        nb = 4
+        nb = 96                                      # ~10 s of CPU work at ~9 blocks/s
         small = {k: v[:nb].cpu() for k, v in b.items()}
-        ref(small)                                   # warm-up (thread pool, allocations)
+        ref({k: v[:4] for k, v in small.items()})    # warm-up (thread pool, allocations)
         t0 = time.perf_counter()
-        exp = ref(small)["embed"]
+        exp = torch.cat([ref({k: v[i:i + 8] for k, v in small.items()})["embed"] for i in range(0, nb, 8)], 0)
         dt = time.perf_counter() - t0
         got = out[:nb].cpu()
         cos = torch.nn.functional.cosine_similarity(got.view(nb * 3, H), exp.view(nb * 3, H), dim=1)
