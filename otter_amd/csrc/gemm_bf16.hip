@@ -71,18 +71,30 @@ constexpr int OFF_AF = 0, OFF_BF = HT, OFF_BS = 2 * HT, OFF_AS = 3 * HT;
 
 __device__ __forceinline__ void bar() { asm volatile("s_barrier" ::: "memory"); }
 
-// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16 resolution):
-// gelu(x) = 0.5 x (1 + erf(x / sqrt 2))
-__device__ __forceinline__ float gelu_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
-    const float h = x * (0.5f * p * t * e);     // 0.5 x (1 - erf(z))
-    return x > 0.0f ? x - h : h;
+// gelu(x) = 0.5 x (1 + erf(x / sqrt 2)) for a bf16 result, two values per instruction:
+// erf(z) ~ z P(z^2) on |z| <= 3.2 (degree-9 P, least-squares fit, |error| <= 9e-6) and clamped
+// outside (1 - erf(3.2) = 6e-6).  No transcendental, so every step is a packed f32 op
+// (v_pk_mul_f32 / v_pk_fma_f32); evaluated in fp32 the result is within 6.1e-5 absolute and
+// 1.4e-5 relative (where |gelu| > 1) of the exact erf form -- far below the bf16 rounding of
+// the store (tests/test_gemm_gpu.py compares against torch's erf GELU).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 gelu_pk(f32x2 x) {
+    f32x2 z = x * 0.70710678118654752440f;
+    z[0] = __builtin_amdgcn_fmed3f(z[0], -3.2f, 3.2f);
+    z[1] = __builtin_amdgcn_fmed3f(z[1], -3.2f, 3.2f);
+    const f32x2 t = z * z;
+    f32x2 p = t * -2.395521082e-09f + 1.418175454e-07f;
+    p = p * t + -3.740854022e-06f;
+    p = p * t + 5.852148138e-05f;
+    p = p * t + -6.120049626e-04f;
+    p = p * t + 4.588824678e-03f;
+    p = p * t + -2.583134492e-02f;
+    p = p * t + 1.118967519e-01f;
+    p = p * t + -3.757361709e-01f;
+    p = p * t + 1.128333932e+00f;
+    const f32x2 hx = x * 0.5f;
+    return hx * (z * p) + hx;
 }
 
 template <int EPI>
@@ -304,7 +316,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
                     }
                     if (EPI == GEMM_EPI_BIAS_GELU) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+                        for (int e = 0; e < 8; e += 2) {
+                            const f32x2 r = gelu_pk(f32x2{v[e], v[e + 1]});
+                            v[e] = r[0];
+                            v[e + 1] = r[1];
+                        }
                     }
                     bf16x8 o;
 #pragma unroll
