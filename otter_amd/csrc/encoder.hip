@@ -470,45 +470,81 @@ __global__ __launch_bounds__(1024 / QB, QB == 2 ? 2 : 4) void attn_full_kernel(A
             for (int rq = 0; rq < 4; ++rq)
                 bv[sub][rq] = *reinterpret_cast<const float4*>(sB + t * 64 + sub * 32 + 8 * rq + 4 * h);
 
+        // does this tile hold a masked key (padding)?  wave-uniform; bias values are 0 or -1e30
+        bool lm = false;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+                lm = lm || (bv[sub][rq].x + bv[sub][rq].y + bv[sub][rq].z + bv[sub][rq].w) != 0.0f;
+        const bool masked = __ballot(lm) != 0ull;
+
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
+            // row maximum in the exponent's units (scale2 > 0: max commutes with the scaling)
             float mx = -INFINITY;
+            if (masked) {
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
+                for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float4 bb = bv[sub][r >> 2];
-                    const float bias = (r & 3) == 0 ? bb.x : (r & 3) == 1 ? bb.y : (r & 3) == 2 ? bb.z : bb.w;
-                    const float v = fmaf(s[qb][sub][r], scale2, bias);
-                    s[qb][sub][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const float4 bb = bv[sub][r >> 2];
+                        const float bias = (r & 3) == 0 ? bb.x : (r & 3) == 1 ? bb.y : (r & 3) == 2 ? bb.z : bb.w;
+                        const float v = fmaf(s[qb][sub][r], scale2, bias);
+                        s[qb][sub][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+            } else {
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][sub][r]);
+                mx *= scale2;
+            }
             {
                 const u32x2v sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
                 mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
             }
-            const float mnew = fmaxf(mrun[qb], mx);
-            const float alpha = __builtin_amdgcn_exp2f(mrun[qb] - mnew);
+            // deferred rescale: the reference maximum moves only when some row's maximum grew by
+            // more than 2^8 (p <= 256 in between: safe in fp32 sums and in the bf16 P operand);
+            // the first tile always takes it (mrun = -inf)
+            if (__ballot(mx > mrun[qb] + 8.0f) != 0ull) {
+                const float mnew = fmaxf(mrun[qb], mx);
+                const float alpha = __builtin_amdgcn_exp2f(mrun[qb] - mnew);
+                lrun[qb] *= alpha;
+                mrun[qb] = mnew;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[qb][d][r] *= alpha;
+            }
+            const float mref = mrun[qb];
             float psum = 0.0f;
+            if (masked) {
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
+                for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(s[qb][sub][r] - mnew);
-                    s[qb][sub][r] = pv;
-                    psum += pv;
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(s[qb][sub][r] - mref);
+                        s[qb][sub][r] = pv;
+                        psum += pv;
+                    }
+            } else {
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(fmaf(s[qb][sub][r], scale2, -mref));
+                        s[qb][sub][r] = pv;
+                        psum += pv;
+                    }
+            }
             {
                 const u32x2v sw =
                     __builtin_amdgcn_permlane32_swap(__float_as_uint(psum), __float_as_uint(psum), false, false);
                 psum = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
             }
-            lrun[qb] = lrun[qb] * alpha + psum;
-            mrun[qb] = mnew;
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[qb][d][r] *= alpha;
+            lrun[qb] += psum;
         }
 
         // O^T += V^T P^T
@@ -569,7 +605,7 @@ int launch_attn_bf16(const AttnArgs& a, hipStream_t st) {
     const int nt = a.Lp >> 6;
     const int lds = 2 * nt * 8192 + nt * 256;
     static const char* v = getenv("OTTER_ATTN_QB");   // A/B switch for tuning runs
-    if (v && v[0] == '2') {
+    if (!(v && v[0] == '1')) {   // default: 8 waves x 64 queries (the 16-wave form spills at 128 VGPRs)
         OTTER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<2>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         hipLaunchKernelGGL(attn_full_kernel<2>, dim3(a.heads, a.B), dim3(512), lds, st, a);
