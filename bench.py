@@ -126,7 +126,7 @@ def encode_leg(rank, world, local_rank, dist, steps, warmup, batch, cpu_ref):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=out.device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if os.environ.get("OTTER_BENCH_REHEARSE") == "1" else out.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank != 0:
@@ -189,13 +189,21 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
+    # rehearsal on a one-GPU box (OTTER_BENCH_REHEARSE=1): every rank uses GPU 0 and the exchange goes through
+    # gloo; the driver's real runs use one GPU per rank and RCCL
+    rehearse = os.environ.get("OTTER_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from otter_amd.index import IndexFlatIP, merge_topk
 
@@ -218,8 +226,15 @@ def main():
     def step():
         D, I = index.search(q, k)
         if world > 1:
-            dist.all_gather_into_tensor(Dg, D)
-            dist.all_gather_into_tensor(Ig, I)
+            if rehearse:    # gloo: stage through the host
+                Dh, Ih = torch.empty((world * nq, k), dtype=torch.float32), torch.empty((world * nq, k), dtype=torch.int64)
+                dist.all_gather_into_tensor(Dh, D.cpu())
+                dist.all_gather_into_tensor(Ih, I.cpu())
+                Dg.copy_(Dh)
+                Ig.copy_(Ih)
+            else:
+                dist.all_gather_into_tensor(Dg, D)
+                dist.all_gather_into_tensor(Ig, I)
             D, I = merge_topk(Dg.view(world, nq, k), Ig.view(world, nq, k), device=local_rank)
         return D, I
 
@@ -240,7 +255,7 @@ def main():
     scan_ms, launches = index.timing()
     index.set_timing(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -249,6 +264,17 @@ def main():
     # (2) the first 65,536 rows re-scored with torch in float64 for 8 queries
     ok = True
     fallback = index.last_fallback
+    if rank == 0 and world > 1:
+        # merged result of the sharded search: sorted, unique global ids in range, and this rank's own shard
+        # result must be a subsequence-by-score of it (every local hit that beats the merged k-th is present)
+        Dl, Il = index.search(q[:64].contiguous(), k)
+        okm = bool((D[:, 1:] <= D[:, :-1]).all().item()) and bool(((I >= 0) & (I < world * n)).all().item())
+        srt = torch.sort(I, dim=1).values
+        okm = okm and bool((srt[:, 1:] != srt[:, :-1]).all().item())
+        for qi in range(64):
+            keep = Il[qi][Dl[qi] > D[qi, -1]]
+            okm = okm and bool(torch.isin(keep, I[qi]).all().item())
+        ok = ok and okm
     if rank == 0 and world == 1:
         De, Ie = index.search(q[:64].contiguous(), k)
         ok = bool(torch.equal(Ie, I[:64])) and bool(torch.equal(De.view(torch.int32), D[:64].view(torch.int32)))
