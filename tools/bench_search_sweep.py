@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="fp32", help="corpus storage: fp32 (IndexFlatIP arithmetic) or bf16")
+    ap.add_argument("--recall", action="store_true",
+                    help="bf16 only: also build the fp32 index and report recall@k of the bf16 ids against it")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
@@ -40,6 +42,10 @@ def main():
         xb[lo:hi] = torch.randn((hi - lo, a.dim), generator=g, device=dev)
     ix = IndexFlatIP(a.dim, device=0, dtype=a.dtype)
     ix.add(xb)
+    ref = None
+    if a.recall and a.dtype == "bf16":
+        ref = IndexFlatIP(a.dim, device=0)
+        ref.add(xb)
     del xb
     torch.cuda.empty_cache()
     g.manual_seed(4321)
@@ -62,12 +68,24 @@ def main():
         kms = ms / max(n, 1)
         gbs = a.rows * a.dim * (2 if a.dtype == 'bf16' else 4) / (kms * 1e-3) / 1e9
         tf = 2.0 * a.rows * a.dim * nq / (kms * 1e-3) / 1e12
-        print(json.dumps({"nq": nq, "k": a.k, "rows": a.rows, "scan_ms": round(kms, 4), "wall_ms": round(wall, 4),
-                          "GBps": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM, 4), "TFLOPs": round(tf, 2),
-                          "mfma_frac": round(tf / PEAK_F32, 4), "queries_per_s": round(nq / (wall * 1e-3), 1),
-                          "dtype": a.dtype, "fallback_queries": ix.last_fallback}),
-              flush=True)
+        rec = {"nq": nq, "k": a.k, "rows": a.rows, "scan_ms": round(kms, 4), "wall_ms": round(wall, 4),
+               "GBps": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM, 4), "TFLOPs": round(tf, 2),
+               "mfma_frac": round(tf / (2500.0 if a.dtype == "bf16" else PEAK_F32), 4),
+               "queries_per_s": round(nq / (wall * 1e-3), 1),
+               "dtype": a.dtype, "fallback_queries": ix.last_fallback}
+        if ref is not None:
+            _, I16 = ix.search(q, a.k)
+            _, I32 = ref.search(q, a.k)
+            I16 = torch.as_tensor(I16).cpu()
+            I32 = torch.as_tensor(I32).cpu()
+            hit = 0
+            for r in range(nq):
+                hit += len(set(I16[r].tolist()) & set(I32[r].tolist()))
+            rec["recall_at_k_vs_fp32"] = round(hit / float(nq * a.k), 5)
+        print(json.dumps(rec), flush=True)
     ix.close()
+    if ref is not None:
+        ref.close()
 
 
 if __name__ == "__main__":
