@@ -336,40 +336,44 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
     auto barA = [&]() { DG(unsigned long long t1 = stamp(); dL += t1 - dt;) bar(); DG(dt = stamp(); dA += dt - t1;) };
     auto barB = [&]() { DG(unsigned long long t1 = stamp(); dM += t1 - dt;) bar(); DG(dt = stamp(); dB += dt - t1;) };
 
-    // ---- prologue: half-tiles 0..5
+    // ---- prologue: half-tiles 0..6
     issue(0); issue(1); issue(2); issue(3);
-    issue(0);
-    if (issue(1)) wait_vmcnt<8>();   // A-first(0), B-first(0) have landed
+    issue(0); issue(1);
+    if (issue(2)) wait_vmcnt<8>();   // A-first(0), B-first(0), B-second(0) have landed
     else wait_vmcnt<0>();
     __syncthreads();                 // ... for every wave; the bias vector is in LDS
     init_acc();
     ldX(X0, smem + OFF_AF);
     if (g == 1) bar();               // group 1 runs one barrier behind
 
+    // Fragments are read from LDS one phase before the MFMAs that use them, so a load segment only
+    // issues its reads (their latency passes under the other group's MFMAs and this group's own);
+    // the one exception is W0, which phase 3 still uses when the next K-step begins.
+    // Segment (u, p) issues half-tile 4u + p + 7 and then waits until 4u + p + 3 has landed.
     for (int cs = 0; cs < total_stages; ++cs) {
         const char* lb = smem + (cs & 1) * BUF;
         const bool as = c_t == 0 && cs > 0;   // first K-step after an epilogue
         // phase 0: quadrant (0, 0)
         ldW(0, lb + OFF_BF);
-        stage_and_wait(2, as);
+        ldW(1, lb + OFF_BS);
+        stage_and_wait(3, as);
         barA();
         mma(X0, 0, 0);
         barB();
         // phase 1: quadrant (0, 1)
-        ldW(1, lb + OFF_BS);
-        stage_and_wait(3, as);
-        barA();
-        mma(X0, 0, 1);
-        barB();
-        // phase 2: quadrant (1, 1)
         ldX(X1, lb + OFF_AS);
         stage_and_wait(0, as);
         barA();
+        mma(X0, 0, 1);
+        barB();
+        // phase 2: quadrant (1, 1); token fragments of the next K-step's quadrant row 0
+        if (cs + 1 < total_stages) ldX(X0, smem + ((cs + 1) & 1) * BUF + OFF_AF);
+        stage_and_wait(1, as);
+        barA();
         mma(X1, 1, 1);
         barB();
-        // phase 3: quadrant (1, 0); token fragments of the next K-step's quadrant row 0
-        if (cs + 1 < total_stages) ldX(X0, smem + ((cs + 1) & 1) * BUF + OFF_AF);
-        stage_and_wait(1, false);
+        // phase 3: quadrant (1, 0)
+        stage_and_wait(2, false);
         barA();
         mma(X1, 1, 0);
         if (++c_t == KT) {
