@@ -201,6 +201,27 @@ int otter_encoder_forward_hidden(otter_encoder* enc,
 int otter_gemm_bf16(int device, int epi, const void* A, const void* W, const float* bias, const void* R,
                     void* C, int64_t M, int N, int K, void* stream);
 
+/* Parity hooks for the LayerNorm folding of the bf16 path (no counterpart call in the reference; the
+ * reference's LayerNorms are torch.nn.LayerNorm inside HF's BertLayer, reached from
+ * retrieval/models/tb_retriever.py:180-185).  All pointers are device pointers.
+ *
+ * otter_ln_fold:  Wout[n,k] = bf16(gamma[k] * W[n,k]);  s_out[n] = sum_k Wout[n,k];
+ *                 c_out[n] = bias[n] + sum_k beta[k] * W[n,k]          (W float32 [N, K]; bias may be NULL)
+ * otter_gemm_bf16_ln, epi 0 / 1, ln_mode 1:  C = LN(A) W^T + bias (then GELU for epi 1) computed as
+ *                 rstd_m * (A Wout^T)[m,n] - rstd_m * mean_m * s_n + c_n  with W = Wout, v0 = s, v1 = c,
+ *                 stat[m] = (rstd_m, -mean_m * rstd_m) float32 pairs; `bias` unused.
+ *                 epi 2, ln_mode 1:  C = A W^T + bias + R and part[4 * N / 256][M] float32 pairs
+ *                 (sum, sum of squares) of the stored rows over 64 columns each.
+ *                 epi 2, ln_mode 2:  as mode 1 with R replaced by (R * rstd + (-mean rstd)) * v0 + v1
+ *                 (v0 = gamma, v1 = beta, stat of the rows of R).
+ * otter_ln_stats: stat[m] = (rstd, -mean * rstd) over N features from P partial pairs per row. */
+int otter_ln_fold(int device, const float* W, const float* gamma, const float* beta, const float* bias, void* Wout,
+                  float* s_out, float* c_out, int N, int K, void* stream);
+int otter_gemm_bf16_ln(int device, int epi, int ln_mode, const void* A, const void* W, const float* bias, const void* R,
+                       void* C, const void* stat, const float* v0, const float* v1, void* part, int64_t M, int N, int K,
+                       void* stream);
+int otter_ln_stats(int device, const void* part, int P, int64_t M, int N, float eps, void* stat, void* stream);
+
 int  otter_encoder_out_dim(const otter_encoder* enc);
 void otter_encoder_destroy(otter_encoder* enc);
 

@@ -57,6 +57,10 @@ SIGNATURES = {
     "otter_encoder_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "otter_encoder_forward_hidden": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "otter_gemm_bf16": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
+    "otter_ln_fold": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
+    "otter_gemm_bf16_ln": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
+                                   c_int, c_int, c_vp]),
+    "otter_ln_stats": (c_int, [c_int, c_vp, c_int, c_i64, c_int, ctypes.c_float, c_vp, c_vp]),
     "otter_encoder_out_dim": (c_int, [c_vp]),
     "otter_encoder_destroy": (None, [c_vp]),
 }

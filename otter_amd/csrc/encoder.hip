@@ -830,6 +830,9 @@ struct LayerW {
     void *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
     const float *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
     const float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+    // bf16 path, LayerNorm folded into the consumers (gemm_bf16.hip): gamma-scaled matrices, s_n, c_n
+    void *wqkv_f = nullptr, *w1_f = nullptr;   // wqkv_f: folded with the PREVIOUS layer's output LayerNorm (layers >= 1)
+    float *sqkv = nullptr, *cqkv = nullptr, *s1 = nullptr, *c1 = nullptr;
 };
 
 }  // namespace
@@ -844,6 +847,8 @@ struct otter_encoder {
     std::vector<void*> owned;   // packed buffers
     // workspace (grow-only)
     otter::DevBuf X, X1, QKV, CTX, TMP, MID, pos, kbias;
+    otter::DevBuf part, stat1, stat2;   // LayerNorm statistics of the fused bf16 path
+    bool ln_fused = false;
     long long ws_rows = 0;
 };
 
@@ -938,6 +943,27 @@ int finalize_t(otter_encoder* e) {
         L.ln1b = e->w[p + "attention.output.LayerNorm.bias"].d;
         L.ln2g = e->w[p + "output.LayerNorm.weight"].d;
         L.ln2b = e->w[p + "output.LayerNorm.bias"].d;
+        if (sizeof(T) == 2 && e->ln_fused) {
+            // FFN up reads LN1's rows: fold (gamma1, beta1) into W1
+            if ((rc = dev_alloc(e, &L.w1_f, I * H * sizeof(T)))) return rc;
+            if ((rc = dev_alloc(e, (void**)&L.s1, I * sizeof(float)))) return rc;
+            if ((rc = dev_alloc(e, (void**)&L.c1, I * sizeof(float)))) return rc;
+            if ((rc = launch_fold_ln(e->w[p + "intermediate.dense.weight"].d, L.ln1g, L.ln1b, L.b1, L.w1_f, L.s1, L.c1,
+                                     (int)I, (int)H, st)))
+                return rc;
+            if (li > 0) {
+                // QKV reads the previous layer's LN2 rows
+                const LayerW& P = e->layers[li - 1];
+                if ((rc = dev_alloc(e, &L.wqkv_f, 3 * H * H * sizeof(T)))) return rc;
+                if ((rc = dev_alloc(e, (void**)&L.sqkv, 3 * H * sizeof(float)))) return rc;
+                if ((rc = dev_alloc(e, (void**)&L.cqkv, 3 * H * sizeof(float)))) return rc;
+                for (int t = 0; t < 3; ++t)
+                    if ((rc = launch_fold_ln(e->w[p + names[t] + ".weight"].d, P.ln2g, P.ln2b, L.bqkv + t * H,
+                                             (char*)L.wqkv_f + t * H * H * sizeof(T), L.sqkv + t * H, L.cqkv + t * H,
+                                             (int)H, (int)H, st)))
+                        return rc;
+            }
+        }
     }
     OTTER_HIP_TRY(hipStreamSynchronize(st));
     return OTTER_OK;
@@ -959,6 +985,12 @@ int ensure_ws(otter_encoder* e, int B, int L) {
         if ((rc = b.b->reserve(b.bytes))) return rc;
         // padding rows must stay finite (they are read as GEMM rows and as masked attention keys)
         OTTER_HIP_TRY(hipMemset(b.b->p, 0, b.b->bytes));
+    }
+    if (e->ln_fused) {
+        const size_t parts = (size_t)4 * (H / 256);
+        if ((rc = e->part.reserve(parts * rows * 8))) return rc;
+        if ((rc = e->stat1.reserve((size_t)rows * 8))) return rc;
+        if ((rc = e->stat2.reserve((size_t)rows * 8))) return rc;
     }
     e->ws_rows = rows;
     return OTTER_OK;
@@ -1027,9 +1059,99 @@ int run_layers_nv(otter_encoder* e, const int64_t* ids, const int64_t* mask, con
     return OTTER_OK;
 }
 
+// bf16 path with both LayerNorms of a layer folded into the GEMMs around them (gemm_bf16.hip):
+// the attention-output and FFN-down GEMMs store the un-normalised sums T1 (X1) and T2 (TMP) plus row
+// statistics; QKV and FFN-up read them through gamma-scaled weights; residuals are normalised on the
+// fly.  Only the last layer's output is materialised (pooling / hidden-state readers need it).
+template <int NV>
+int run_layers_fused(otter_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* types, int B, int L,
+                     int n_layers, hipStream_t st) {
+    typedef bf16_t T;
+    const auto& c = e->cfg;
+    const long long M = (long long)B * L, M_pad = round_up64(M, 256);
+    const int H = c.hidden_size, I = c.intermediate_size;
+    const int Lp = round_up(L, 64), P = 4 * (H / 256);
+    int rc;
+    hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(64), 0, st, (const long long*)ids, (const long long*)mask,
+                       (int*)e->pos.p, (float*)e->kbias.p, L, Lp, c.pad_token_id, c.position_mode == OTTER_POS_ROBERTA);
+    const unsigned rowgrid = (unsigned)((M + 3) / 4);
+    hipLaunchKernelGGL((embed_ln_kernel<T, NV>), dim3(rowgrid), dim3(256), 0, st, (const long long*)ids,
+                       (const int*)e->pos.p, (const long long*)types, e->w["embeddings.word_embeddings.weight"].d,
+                       e->w["embeddings.position_embeddings.weight"].d, e->w["embeddings.token_type_embeddings.weight"].d,
+                       e->w["embeddings.LayerNorm.weight"].d, e->w["embeddings.LayerNorm.bias"].d, (T*)e->X.p, (int)M, H,
+                       c.vocab_size, c.max_position_embeddings, c.type_vocab_size, c.layer_norm_eps);
+    OTTER_HIP_TRY(hipGetLastError());
+    for (int li = 0; li < n_layers; ++li) {
+        const LayerW& W = e->layers[li];
+        GemmLN ln;
+        if (li == 0) {
+            if ((rc = launch_gemm_bf16(GEMM_EPI_BIAS, e->X.p, W.wqkv, W.bqkv, nullptr, e->QKV.p, M_pad, 3 * H, H, e->ncu, st)))
+                return rc;
+        } else {
+            ln = GemmLN();
+            ln.mode = 1; ln.stat = e->stat2.p; ln.v0 = W.sqkv; ln.v1 = W.cqkv;
+            if ((rc = launch_gemm_bf16_ln(GEMM_EPI_BIAS, e->TMP.p, W.wqkv_f, nullptr, nullptr, e->QKV.p, M_pad, 3 * H, H, ln,
+                                          e->ncu, st)))
+                return rc;
+        }
+        AttnArgs a;
+        a.QKV = e->QKV.p; a.CTX = e->CTX.p; a.kbias = (const float*)e->kbias.p;
+        a.B = B; a.L = L; a.Lp = Lp; a.H = H; a.heads = c.num_attention_heads;
+        a.scale = 1.0f / sqrtf((float)(H / c.num_attention_heads));
+        if (L <= 512) {
+            if ((rc = launch_attn_bf16(a, st))) return rc;
+        } else {
+            hipLaunchKernelGGL(attn_kernel<T>, dim3((L + 127) / 128, c.num_attention_heads, B), dim3(256), 0, st, a);
+            OTTER_HIP_TRY(hipGetLastError());
+        }
+        // T1 = x + ctx Wo^T + bo, x = the embedding output (layer 0) or LN2 of the previous layer's T2
+        ln = GemmLN();
+        ln.part = e->part.p;
+        if (li == 0) {
+            ln.mode = 1;
+            rc = launch_gemm_bf16_ln(GEMM_EPI_BIAS_RESID, e->CTX.p, W.wo, W.bo, e->X.p, e->X1.p, M_pad, H, H, ln, e->ncu, st);
+        } else {
+            const LayerW& Pv = e->layers[li - 1];
+            ln.mode = 2; ln.stat = e->stat2.p; ln.v0 = Pv.ln2g; ln.v1 = Pv.ln2b;
+            rc = launch_gemm_bf16_ln(GEMM_EPI_BIAS_RESID, e->CTX.p, W.wo, W.bo, e->TMP.p, e->X1.p, M_pad, H, H, ln, e->ncu, st);
+        }
+        if (rc) return rc;
+        if ((rc = launch_ln_stats(e->part.p, P, M_pad, H, c.layer_norm_eps, e->stat1.p, st))) return rc;
+        // MID = gelu(LN1(T1) W1^T + b1)
+        ln = GemmLN();
+        ln.mode = 1; ln.stat = e->stat1.p; ln.v0 = W.s1; ln.v1 = W.c1;
+        if ((rc = launch_gemm_bf16_ln(GEMM_EPI_BIAS_GELU, e->X1.p, W.w1_f, nullptr, nullptr, e->MID.p, M_pad, I, H, ln, e->ncu,
+                                      st)))
+            return rc;
+        // T2 = LN1(T1) + MID W2^T + b2   (T2 overwrites the previous layer's T2: its last reader was this
+        // layer's attention-output GEMM)
+        ln = GemmLN();
+        ln.mode = 2; ln.stat = e->stat1.p; ln.v0 = W.ln1g; ln.v1 = W.ln1b; ln.part = e->part.p;
+        if ((rc = launch_gemm_bf16_ln(GEMM_EPI_BIAS_RESID, e->MID.p, W.w2, W.b2, e->X1.p, e->TMP.p, M_pad, H, I, ln, e->ncu,
+                                      st)))
+            return rc;
+        if (li + 1 < n_layers) {
+            if ((rc = launch_ln_stats(e->part.p, P, M_pad, H, c.layer_norm_eps, e->stat2.p, st))) return rc;
+        } else {
+            hipLaunchKernelGGL((ln_kernel<T, NV>), dim3(rowgrid), dim3(256), 0, st, (const T*)e->TMP.p, W.ln2g, W.ln2b,
+                               (T*)e->X.p, (int)M, H, c.layer_norm_eps);
+            OTTER_HIP_TRY(hipGetLastError());
+        }
+    }
+    return OTTER_OK;
+}
+
 template <typename T>
 int run_layers(otter_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* types, int B, int L,
                int n_layers, hipStream_t st) {
+    if (sizeof(T) == 2 && e->ln_fused) {
+        switch (e->cfg.hidden_size / 256) {
+            case 1: return run_layers_fused<1>(e, ids, mask, types, B, L, n_layers, st);
+            case 2: return run_layers_fused<2>(e, ids, mask, types, B, L, n_layers, st);
+            case 3: return run_layers_fused<3>(e, ids, mask, types, B, L, n_layers, st);
+            case 4: return run_layers_fused<4>(e, ids, mask, types, B, L, n_layers, st);
+        }
+    }
     switch (e->cfg.hidden_size / 256) {
         case 1: return run_layers_nv<T, 1>(e, ids, mask, types, B, L, n_layers, st);
         case 2: return run_layers_nv<T, 2>(e, ids, mask, types, B, L, n_layers, st);
@@ -1160,6 +1282,11 @@ int otter_encoder_finalize(otter_encoder* e, int compute_dtype) {
         if (e->w.find(n) == e->w.end()) return set_err(OTTER_ESTATE, "finalize: tensor '%s' was never set", n.c_str());
     DeviceGuard g(e->device);
     if (!g.ok) return set_err(OTTER_EHIP, "finalize: hipSetDevice(%d) failed", e->device);
+    // bf16: LayerNorm folded into the GEMMs around it (OTTER_NO_LN_FUSE=1 keeps the separate kernels, for A/B runs)
+    const char* nofuse = getenv("OTTER_NO_LN_FUSE");
+    // (the folded consumers keep two epilogue vectors of their output width in LDS: width <= 3072)
+    e->ln_fused = compute_dtype == OTTER_BF16 && !(nofuse && nofuse[0] == '1') && e->cfg.intermediate_size <= 3072 &&
+                  3 * e->cfg.hidden_size <= 3072;
     int rc = compute_dtype == OTTER_BF16 ? finalize_t<bf16_t>(e) : finalize_t<float>(e);
     if (rc) return rc;
     e->dtype = compute_dtype;
@@ -1221,6 +1348,35 @@ int otter_gemm_bf16(int device, int epi, const void* A, const void* W, const flo
     return launch_gemm_bf16(epi, A, W, bias, R, C, M, N, K, prop.multiProcessorCount, (hipStream_t)stream);
 }
 
+int otter_gemm_bf16_ln(int device, int epi, int ln_mode, const void* A, const void* W, const float* bias, const void* R,
+                       void* C, const void* stat, const float* v0, const float* v1, void* part, int64_t M, int N, int K,
+                       void* stream) {
+    if (!A || !W || !C) return set_err(OTTER_EINVAL, "gemm_bf16_ln: NULL operand");
+    DeviceGuard g(device);
+    if (!g.ok) return set_err(OTTER_EHIP, "gemm_bf16_ln: hipSetDevice(%d) failed", device);
+    hipDeviceProp_t prop;
+    OTTER_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    GemmLN ln;
+    ln.mode = ln_mode; ln.stat = stat; ln.v0 = v0; ln.v1 = v1; ln.part = part;
+    return launch_gemm_bf16_ln(epi, A, W, bias, R, C, M, N, K, ln, prop.multiProcessorCount, (hipStream_t)stream);
+}
+
+int otter_ln_stats(int device, const void* part, int P, int64_t M, int N, float eps, void* stat, void* stream) {
+    if (!part || !stat || P <= 0 || M <= 0 || N <= 0) return set_err(OTTER_EINVAL, "ln_stats: bad argument");
+    DeviceGuard g(device);
+    if (!g.ok) return set_err(OTTER_EHIP, "ln_stats: hipSetDevice(%d) failed", device);
+    return launch_ln_stats(part, P, M, N, eps, stat, (hipStream_t)stream);
+}
+
+int otter_ln_fold(int device, const float* W, const float* gamma, const float* beta, const float* bias, void* Wout,
+                  float* s_out, float* c_out, int N, int K, void* stream) {
+    if (!W || !gamma || !beta || !Wout || !s_out || !c_out || N <= 0 || K <= 0)
+        return set_err(OTTER_EINVAL, "ln_fold: bad argument");
+    DeviceGuard g(device);
+    if (!g.ok) return set_err(OTTER_EHIP, "ln_fold: hipSetDevice(%d) failed", device);
+    return launch_fold_ln(W, gamma, beta, bias, Wout, s_out, c_out, N, K, (hipStream_t)stream);
+}
+
 int otter_encoder_out_dim(const otter_encoder* e) {
     if (!e) return -1;
     return e->cfg.three_cat ? 3 * e->cfg.hidden_size : e->cfg.hidden_size;
@@ -1234,6 +1390,7 @@ void otter_encoder_destroy(otter_encoder* e) {
     for (void* p : e->owned) (void)hipFree(p);
     e->X.release(); e->X1.release(); e->QKV.release(); e->CTX.release();
     e->TMP.release(); e->MID.release(); e->pos.release(); e->kbias.release();
+    e->part.release(); e->stat1.release(); e->stat2.release();
     delete e;
 }
 

@@ -14,9 +14,11 @@
 //   * LDS holds two K-steps, each as four 16 KiB half-tiles in the order they are consumed:
 //     A-first (token rows of quadrant row 0 of both groups), B-first (feature rows of quadrant
 //     column 0 of all four waves), B-second, A-second.  One half-tile is DMA'd per phase
-//     (global_load_lds_dwordx4, 2 per wave), six half-tiles ahead of the consumer, across output
+//     (global_load_lds_dwordx4, 2 per wave), seven half-tiles ahead of the consumer, across output
 //     tiles (the stream of K-steps is flat over this workgroup's tiles), and retired with a
 //     counted s_waitcnt vmcnt(8): four half-tiles stay in flight, the loop never drains to zero.
+//   * Fragments are read from LDS one phase before the MFMAs that use them (a load segment only
+//     issues reads and DMA; the counted lgkmcnt lands inside the MFMA segment).
 //   * 128-byte LDS rows, 16-B chunks XOR-swizzled through the DMA *source* address
 //     (chunk ^ ((row >> 1) & 7)): every ds_read_b128 lane group hits 16 distinct slots.
 //   * Epilogue: bias is the accumulators' initial value; v_permlane16_swap pairs two feature
@@ -25,9 +27,16 @@
 //
 // Hazard bookkeeping (segments are the intervals between barriers; group 1 is one behind):
 //   RAW  a half-tile retired by the wait in segment j is read no earlier than segment j + 2;
-//   WAR  a slot is refilled no earlier than 3 segments after its last ds_read was issued.
-// With half-tile h = 4u + p + 6 issued in load phase p of K-step u both hold by construction
-// (table in DESIGN.md §4).
+//   WAR  a slot is refilled no earlier than 3 segments after the MFMA segment that consumed it.
+// With half-tile h = 4u + p + 7 issued in load phase p of K-step u, and the wait of that phase
+// covering everything up to 4u + p + 3, both hold by construction (table in DESIGN.md §4).
+//
+// LayerNorm folded around the GEMM (template parameter LN, GemmLN in otter_gemm.h): the producer
+// (residual epilogue) stores the un-normalised sum and per-row (sum, sum of squares) partials of
+// what it stored; the consumer multiplies the un-normalised rows with gamma-scaled weights and
+// applies  C = rstd_m * acc - rstd_m * mean_m * s_n + c_n  in its epilogue
+// (s_n = sum_k W'[n,k], c_n = bias_n + sum_k beta_k W[n,k]); a residual that is itself an
+// un-normalised row is normalised on the fly.  The normalised activation is never written.
 #include <algorithm>
 #include <vector>
 
@@ -49,6 +58,12 @@ struct PPArgs {
     bf16_t* C;          // [M_pad][ldc] bf16
     int tiles_m, tiles_n, KT, N;
     int lda, ldw, ldc;  // elements
+    // LayerNorm folding (LN != 0)
+    const float2* stat; // [M_pad] (rstd, -mean * rstd) of the rows of A (EPI 0/1) or of R (EPI 2, LN 2)
+    const float* v0;    // [N] s_n (EPI 0/1) or gamma (EPI 2, LN 2)
+    const float* v1;    // [N] c_n (EPI 0/1) or beta  (EPI 2, LN 2)
+    float2* part;       // EPI 2: [4 * tiles_n][M_pad] (sum, sum of squares) over 64 columns of what was stored
+    long long M_pad;
     unsigned long long* dbg;   // GEMM_DIAG builds only
 };
 
@@ -97,10 +112,22 @@ __device__ __forceinline__ f32x2 gelu_pk(f32x2 x) {
     return hx * (z * p) + hx;
 }
 
-template <int EPI>
+template <int EPI, int LN>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
+    constexpr bool LNIN = EPI != GEMM_EPI_BIAS_RESID && LN == 1;    // A rows are un-normalised
+    constexpr bool STATS = EPI == GEMM_EPI_BIAS_RESID && LN >= 1;   // emit row statistics of C
+    constexpr bool LNRES = EPI == GEMM_EPI_BIAS_RESID && LN == 2;   // R rows are un-normalised
+    constexpr bool ROWSTAT = LNIN || LNRES;                          // the epilogue needs (rstd, -mean rstd) per row
+    // VMEM operations a wave issues between a tile's last MFMA and the next tile's first half-tile
+    constexpr int EPI_STORES = 16 + (STATS ? 8 : 0) + (ROWSTAT ? 1 : 0);
+    constexpr int NVEC = LNIN ? 2 : LNRES ? 3 : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sbias = reinterpret_cast<float*>(smem + 2 * BUF);   // [N] bias (zeros without one)
+    float* sbias = reinterpret_cast<float*>(smem + 2 * BUF);   // [N] bias (zeros without one); c_n under LNIN
+    float* sv0 = sbias + a.N;                                  // [N] s_n (LNIN) / gamma (LNRES)
+    float* sv1 = sv0 + a.N;                                    // [N] beta (LNRES)
+    // per wave: the 128 (rstd, -mean rstd) pairs of its group's token rows, DMA'd one tile ahead
+    // (own region, own vmcnt: no barrier involved)
+    float2* sstat = reinterpret_cast<float2*>(sbias + NVEC * a.N) + 128 * (threadIdx.x >> 6);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = wave >> 2, wn = wave & 3;
@@ -142,7 +169,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
         }
     };
 
-    for (int i = tid; i < a.N; i += 512) sbias[i] = a.bias ? a.bias[i] : 0.0f;
+    if (LNIN) {
+        for (int i = tid; i < a.N; i += 512) { sbias[i] = a.v1[i]; sv0[i] = a.v0[i]; }
+    } else {
+        for (int i = tid; i < a.N; i += 512) sbias[i] = a.bias ? a.bias[i] : 0.0f;
+        if (LNRES)
+            for (int i = tid; i < a.N; i += 512) { sv0[i] = a.v0[i]; sv1[i] = a.v1[i]; }
+    }
 
     // ---- producer: per-lane source offsets (bytes), fixed for the kernel
     u32 voffA[2], voffB[2];
@@ -157,6 +190,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
     }
     const u32 lds0 = (u32)(uintptr_t)(OTTER_AS3 char*)smem;
     const u32 dma_dst = (u32)(wave * 2) * 1024u;
+    auto issue_rowstat = [&](int tm) {
+        if (ROWSTAT)
+            dma16s(reinterpret_cast<const char*>(a.stat) + ((size_t)tm * 256 + g * 128) * sizeof(float2), (u32)lane * 16u,
+                   lds0 + (u32)(2 * BUF) + (u32)(NVEC * a.N) * 4u + (u32)wave * 1024u);
+    };
 
     int is_stage = 0, is_t = 0, is_j = 0;
     bool is_valid = false;
@@ -214,7 +252,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
     auto init_acc = [&]() {
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(sbias + c_tn * 256 + wn * 64 + nb * 16 + 4 * fq);
+            const f32x4 b = LNIN ? f32x4{0.f, 0.f, 0.f, 0.f}
+                                 : *reinterpret_cast<const f32x4*>(sbias + c_tn * 256 + wn * 64 + nb * 16 + 4 * fq);
 #pragma unroll
             for (int mb = 0; mb < 8; ++mb) acc[mb][nb] = b;
         }
@@ -267,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
         DG(unsigned long long tw1 = stamp(); dI += tw1 - tw0;)
 #if !defined(GEMM_ABL) || GEMM_ABL != 2
         if (issued) {
-            if (after_store) wait_vmcnt<24>();
+            if (after_store) wait_vmcnt<8 + EPI_STORES>();
             else wait_vmcnt<8>();
         } else {
             wait_vmcnt<0>();
@@ -280,21 +319,29 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
         const size_t row0 = (size_t)c_tm * 256 + g * 128 + fr;
         // two halves of 4 token blocks: the residual's 8 loads of a half are all issued before
         // the first is consumed (one memory latency per half instead of one per 16-B unit)
+        // (2 token blocks per batch when the residual is normalised on the fly: registers)
+        constexpr int MBB = LNRES ? 2 : 4;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            uint4 rr[4][2];
+        for (int half = 0; half < 8 / MBB; ++half) {
+            uint4 rr[MBB][2];
+            float2 stt[MBB];
+            if (ROWSTAT) {
+#pragma unroll
+                for (int m4 = 0; m4 < MBB; ++m4) stt[m4] = sstat[(half * MBB + m4) * 16 + fr];
+            }
             if (EPI == GEMM_EPI_BIAS_RESID) {
 #pragma unroll
-                for (int m4 = 0; m4 < 4; ++m4)
+                for (int m4 = 0; m4 < MBB; ++m4)
 #pragma unroll
                     for (int jn = 0; jn < 2; ++jn)
                         rr[m4][jn] = *reinterpret_cast<const uint4*>(
-                            a.R + (row0 + (half * 4 + m4) * 16) * (size_t)a.ldc + col0 + jn * 32);
+                            a.R + (row0 + (half * MBB + m4) * 16) * (size_t)a.ldc + col0 + jn * 32);
             }
 #pragma unroll
-            for (int m4 = 0; m4 < 4; ++m4) {
-                const int mb = half * 4 + m4;
+            for (int m4 = 0; m4 < MBB; ++m4) {
+                const int mb = half * MBB + m4;
                 const size_t rowoff = (row0 + mb * 16) * (size_t)a.ldc;
+                float rs = 0.f, rss = 0.f;
 #pragma unroll
                 for (int jn = 0; jn < 2; ++jn) {
                     float v[8];
@@ -306,13 +353,41 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
                         v[i] = __uint_as_float(s[0]);
                         v[4 + i] = __uint_as_float(s[1]);
                     }
+                    if (LNIN) {
+                        // LN(A) W^T = rstd (A W'^T) - rstd mean s + c
+                        const float* ps = sv0 + col0 + jn * 32;
+                        const float* pc = sbias + col0 + jn * 32;
+#pragma unroll
+                        for (int e4 = 0; e4 < 2; ++e4) {
+                            const f32x4 s4 = *reinterpret_cast<const f32x4*>(ps + 4 * e4);
+                            const f32x4 c4 = *reinterpret_cast<const f32x4*>(pc + 4 * e4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                v[4 * e4 + e] = fmaf(stt[m4].x, v[4 * e4 + e], fmaf(stt[m4].y, s4[e], c4[e]));
+                        }
+                    }
                     if (EPI == GEMM_EPI_BIAS_RESID) {
                         const u32 w[4] = {rr[m4][jn].x, rr[m4][jn].y, rr[m4][jn].z, rr[m4][jn].w};
+                        float r[8];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            v[2 * e] += __uint_as_float(w[e] << 16);
-                            v[2 * e + 1] += __uint_as_float(w[e] & 0xFFFF0000u);
+                            r[2 * e] = __uint_as_float(w[e] << 16);
+                            r[2 * e + 1] = __uint_as_float(w[e] & 0xFFFF0000u);
                         }
+                        if (LNRES) {
+                            const float* pg = sv0 + col0 + jn * 32;
+                            const float* pb = sv1 + col0 + jn * 32;
+#pragma unroll
+                            for (int e4 = 0; e4 < 2; ++e4) {
+                                const f32x4 g4 = *reinterpret_cast<const f32x4*>(pg + 4 * e4);
+                                const f32x4 b4 = *reinterpret_cast<const f32x4*>(pb + 4 * e4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    r[4 * e4 + e] = fmaf(fmaf(r[4 * e4 + e], stt[m4].x, stt[m4].y), g4[e], b4[e]);
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += r[e];
                     }
                     if (EPI == GEMM_EPI_BIAS_GELU) {
 #pragma unroll
@@ -325,7 +400,29 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
                     bf16x8 o;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+                    if (STATS) {
+                        // statistics of the values as stored (bf16), so that the consumer's
+                        // normalisation is consistent with the rows it reads
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float f = (float)o[e];
+                            rs += f;
+                            rss = fmaf(f, f, rss);
+                        }
+                    }
                     *reinterpret_cast<float4*>(a.C + rowoff + col0 + jn * 32) = __builtin_bit_cast(float4, o);
+                }
+                if (STATS) {
+                    // the four lanes fr, fr+16, fr+32, fr+48 hold the other features of this token
+                    u32x2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(rs), __float_as_uint(rs), false, false);
+                    rs = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+                    t = __builtin_amdgcn_permlane16_swap(__float_as_uint(rss), __float_as_uint(rss), false, false);
+                    rss = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+                    t = __builtin_amdgcn_permlane32_swap(__float_as_uint(rs), __float_as_uint(rs), false, false);
+                    rs = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+                    t = __builtin_amdgcn_permlane32_swap(__float_as_uint(rss), __float_as_uint(rss), false, false);
+                    rss = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+                    if (fq == 0) a.part[(size_t)(c_tn * 4 + wn) * a.M_pad + row0 + mb * 16] = float2{rs, rss};
                 }
             }
         }
@@ -336,7 +433,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
     auto barA = [&]() { DG(unsigned long long t1 = stamp(); dL += t1 - dt;) bar(); DG(dt = stamp(); dA += dt - t1;) };
     auto barB = [&]() { DG(unsigned long long t1 = stamp(); dM += t1 - dt;) bar(); DG(dt = stamp(); dB += dt - t1;) };
 
-    // ---- prologue: half-tiles 0..6
+    // ---- prologue: row statistics of the first tile, half-tiles 0..6
+    issue_rowstat(c_tm);
     issue(0); issue(1); issue(2); issue(3);
     issue(0); issue(1);
     if (issue(2)) wait_vmcnt<8>();   // A-first(0), B-first(0), B-second(0) have landed
@@ -389,6 +487,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
             if (++c_j < n_my) {
                 coords(c_j, c_tm, c_tn);
                 init_acc();
+                issue_rowstat(c_tm);
             }
         } else {
             barB();
@@ -403,17 +502,88 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
 #endif
 }
 
+// (rstd, -mean * rstd) per row from the producers' partials: one thread per row
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float2* __restrict__ part, int P, long long M_pad, int N,
+                                                       float eps, float2* __restrict__ stat) {
+    const long long r = blockIdx.x * 256ll + threadIdx.x;
+    if (r >= M_pad) return;
+    float s = 0.f, ss = 0.f;
+    for (int p = 0; p < P; ++p) {
+        const float2 v = part[(size_t)p * M_pad + r];
+        s += v.x;
+        ss += v.y;
+    }
+    const float mean = s / N;
+    const float var = fmaxf(ss / N - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    stat[r] = float2{rstd, -mean * rstd};
+}
+
+// W'[n,k] = bf16(gamma_k W[n,k]);  s_n = sum_k W'[n,k];  c_n = bias_n + sum_k beta_k W[n,k].  One block per n.
+__global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ bias,
+                                                      bf16_t* __restrict__ Wout, float* __restrict__ s_out,
+                                                      float* __restrict__ c_out, int K) {
+    __shared__ float red[2][4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    float s = 0.f, c = 0.f;
+    for (int k = tid; k < K; k += 256) {
+        const float w = W[(size_t)n * K + k];
+        const __bf16 wq = (__bf16)(gamma[k] * w);
+        Wout[(size_t)n * K + k] = __builtin_bit_cast(bf16_t, wq);
+        s += (float)wq;
+        c = fmaf(beta[k], w, c);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        c += __shfl_xor(c, o);
+    }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = c; }
+    __syncthreads();
+    if (tid == 0) {
+        s_out[n] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        c_out[n] = (bias ? bias[n] : 0.f) + red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
 }  // namespace
 
 namespace otter {
 
+int launch_ln_stats(const void* part, int P, long long M_pad, int N, float eps, void* stat, hipStream_t st) {
+    hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)((M_pad + 255) / 256)), dim3(256), 0, st, (const float2*)part, P,
+                       M_pad, N, eps, (float2*)stat);
+    OTTER_HIP_TRY(hipGetLastError());
+    return OTTER_OK;
+}
+
+int launch_fold_ln(const float* W, const float* gamma, const float* beta, const float* bias, void* Wout, float* s_out,
+                   float* c_out, int N, int K, hipStream_t st) {
+    hipLaunchKernelGGL(fold_ln_kernel, dim3(N), dim3(256), 0, st, W, gamma, beta, bias, (bf16_t*)Wout, s_out, c_out, K);
+    OTTER_HIP_TRY(hipGetLastError());
+    return OTTER_OK;
+}
+
 int launch_gemm_bf16(int epi, const void* A, const void* W, const float* bias, const void* R, void* C,
                      long long M_pad, int N, int K, int ncu, hipStream_t st) {
+    GemmLN none;
+    return launch_gemm_bf16_ln(epi, A, W, bias, R, C, M_pad, N, K, none, ncu, st);
+}
+
+int launch_gemm_bf16_ln(int epi, const void* A, const void* W, const float* bias, const void* R, void* C,
+                        long long M_pad, int N, int K, const GemmLN& ln, int ncu, hipStream_t st) {
     if (M_pad <= 0 || M_pad % 256 || N <= 0 || N % 256 || K <= 0 || K % 64)
         return set_err(OTTER_EINVAL, "gemm_bf16: M_pad=%lld N=%d K=%d must be multiples of 256/256/64", M_pad, N, K);
+    if (epi < 0 || epi > 2) return set_err(OTTER_EINVAL, "gemm_bf16: epilogue %d", epi);
     if (epi == GEMM_EPI_BIAS_RESID && !R) return set_err(OTTER_EINVAL, "gemm_bf16: residual epilogue without R");
     if ((long long)255 * std::max(N, K) * 2 + 128 > 0x7FFFFFFFll || M_pad / 256 * (N / 256) > 0x7FFFFFFFll)
         return set_err(OTTER_EINVAL, "gemm_bf16: shape too large");
+    const bool resid = epi == GEMM_EPI_BIAS_RESID;
+    if (ln.mode < 0 || ln.mode > 2 || (!resid && ln.mode == 2))
+        return set_err(OTTER_EINVAL, "gemm_bf16: LayerNorm mode %d with epilogue %d", ln.mode, epi);
+    if (ln.mode && resid && !ln.part) return set_err(OTTER_EINVAL, "gemm_bf16: statistics output missing");
+    if (((ln.mode == 1 && !resid) || ln.mode == 2) && (!ln.stat || !ln.v0 || !ln.v1))
+        return set_err(OTTER_EINVAL, "gemm_bf16: LayerNorm folding needs stat, v0, v1");
     PPArgs a;
     a.A = (const char*)A;
     a.W = (const char*)W;
@@ -427,11 +597,27 @@ int launch_gemm_bf16(int epi, const void* A, const void* W, const float* bias, c
     a.lda = K;
     a.ldw = K;
     a.ldc = N;
-    void (*kern)(PPArgs) = epi == GEMM_EPI_BIAS ? gemm_pp_kernel<GEMM_EPI_BIAS>
-                           : epi == GEMM_EPI_BIAS_GELU ? gemm_pp_kernel<GEMM_EPI_BIAS_GELU>
-                                                       : gemm_pp_kernel<GEMM_EPI_BIAS_RESID>;
-    const int lds = 2 * BUF + N * (int)sizeof(float);
-    if (lds > 160 * 1024) return set_err(OTTER_EINVAL, "gemm_bf16: N=%d too wide for the LDS bias vector", N);
+    a.stat = (const float2*)ln.stat;
+    a.v0 = ln.v0;
+    a.v1 = ln.v1;
+    a.part = (float2*)ln.part;
+    a.M_pad = M_pad;
+    void (*kern)(PPArgs) = nullptr;
+    int nvec = 1;
+    if (epi == GEMM_EPI_BIAS) {
+        kern = ln.mode ? gemm_pp_kernel<GEMM_EPI_BIAS, 1> : gemm_pp_kernel<GEMM_EPI_BIAS, 0>;
+        nvec = ln.mode ? 2 : 1;
+    } else if (epi == GEMM_EPI_BIAS_GELU) {
+        kern = ln.mode ? gemm_pp_kernel<GEMM_EPI_BIAS_GELU, 1> : gemm_pp_kernel<GEMM_EPI_BIAS_GELU, 0>;
+        nvec = ln.mode ? 2 : 1;
+    } else {
+        kern = ln.mode == 2 ? gemm_pp_kernel<GEMM_EPI_BIAS_RESID, 2>
+               : ln.mode == 1 ? gemm_pp_kernel<GEMM_EPI_BIAS_RESID, 1> : gemm_pp_kernel<GEMM_EPI_BIAS_RESID, 0>;
+        nvec = ln.mode == 2 ? 3 : 1;
+    }
+    const bool rowstat = ln.mode == 2 || (ln.mode == 1 && !resid);
+    const int lds = 2 * BUF + nvec * N * (int)sizeof(float) + (rowstat ? 8 * 1024 : 0);
+    if (lds > 160 * 1024) return set_err(OTTER_EINVAL, "gemm_bf16: N=%d too wide for the LDS epilogue vectors", N);
     const int ntiles = a.tiles_m * a.tiles_n;
     OTTER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int grid = std::min(ntiles, std::max(1, ncu));
