@@ -5,7 +5,11 @@ Replaces the reference's multi-GPU modes:
   * faiss.index_cpu_to_all_gpus (scripts/eval_ottqa_retrieval.py:110-112: replicas of the whole
     index) -> shard g holds rows [g*ceil(N/G), min(N, (g+1)*ceil(N/G))); every rank searches its
     shard for ALL queries (ids already global via id_base), then ONE all-gather of the
-    (score, id) candidates [nq, k] per rank and a G-way merge on every rank.
+    (score, id) candidates [nq, k] per rank and a G-way merge on every rank.  When the gathered
+    candidates would be large (config 5: 16,384 queries x top-1000 = 197 MB per rank, 1.57 GB
+    gathered) the exchange is sliced by queries instead: an all-to-all hands rank r every shard's
+    candidates for ITS ceil(nq/G) queries (point-to-point messages, one xGMI link each, no ring),
+    rank r merges them, and one all-gather of the merged [nq/G, k] slices follows.
   * nn.DataParallel over the encoder (scripts/encode_corpus.py:112-113: weights re-broadcast and
     outputs gathered every step) -> rank r encodes its own contiguous row range with resident
     weights; no data-path collective (one all-gather of row counts at the end).
@@ -29,7 +33,13 @@ class ShardedIndexFlatIP:
     this rank's GPU); merge_fn(Dc, Ic) -> (D, I) merges [G, nq, k] candidates (default: the GPU
     merge kernel).  Both are injectable so that the collective protocol is testable on CPU."""
 
-    def __init__(self, d, group=None, device=None, index_factory=None, merge_fn=None):
+    # candidate bytes over all ranks from which the exchange is sliced by queries ("auto")
+    SLICED_FROM_BYTES = 64 << 20
+
+    def __init__(self, d, group=None, device=None, index_factory=None, merge_fn=None, exchange="auto"):
+        if exchange not in ("auto", "gather", "sliced"):
+            raise ValueError("exchange must be 'auto', 'gather' or 'sliced'")
+        self.exchange = exchange
         self.d = int(d)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -80,6 +90,11 @@ class ShardedIndexFlatIP:
         D = D.contiguous()
         I = I.contiguous()
         nq, kk = D.shape
+        mode = self.exchange
+        if mode == "auto":
+            mode = "sliced" if self.world * nq * kk * 12 >= self.SLICED_FROM_BYTES else "gather"
+        if mode == "sliced":
+            return self._exchange_sliced(D, I)
         # concatenated along dim 0 (the layout every backend's all_gather_into_tensor accepts)
         Dg = torch.empty((self.world * nq, kk), dtype=D.dtype, device=D.device)
         Ig = torch.empty((self.world * nq, kk), dtype=I.dtype, device=I.device)
@@ -87,6 +102,40 @@ class ShardedIndexFlatIP:
         dist.all_gather_into_tensor(Dg, D, group=self.group)
         dist.all_gather_into_tensor(Ig, I, group=self.group)
         return self._merge(Dg.view(self.world, nq, kk), Ig.view(self.world, nq, kk))
+
+
+def _exchange_sliced_impl(self, D, I):
+    """SURVEY.md §8e option B.  Rank r owns queries [r*per, (r+1)*per), per = ceil(nq/G); rows past nq
+    are padding (score -FLT_MAX, id -1: the "missing" convention the merge already handles)."""
+    G = self.world
+    nq, kk = D.shape
+    per = -(-nq // G)
+    pad = per * G
+    if pad != nq:
+        Dp = torch.full((pad, kk), -3.4028234663852886e38, dtype=D.dtype, device=D.device)
+        Ip = torch.full((pad, kk), -1, dtype=I.dtype, device=I.device)
+        Dp[:nq] = D
+        Ip[:nq] = I
+    else:
+        Dp, Ip = D, I
+    # all-to-all with equal splits: chunk r of my rows goes to rank r; I receive chunk `rank` of every rank
+    Dr = torch.empty_like(Dp)
+    Ir = torch.empty_like(Ip)
+    dist.all_to_all_single(Dr, Dp, group=self.group)
+    dist.all_to_all_single(Ir, Ip, group=self.group)
+    Dm, Im = self._merge(Dr.view(G, per, kk), Ir.view(G, per, kk))
+    if not torch.is_tensor(Dm):
+        Dm, Im = torch.from_numpy(Dm), torch.from_numpy(Im)
+    Dm = Dm.to(D.device).contiguous()
+    Im = Im.to(I.device).contiguous()
+    Dg = torch.empty((pad, kk), dtype=D.dtype, device=D.device)
+    Ig = torch.empty((pad, kk), dtype=I.dtype, device=I.device)
+    dist.all_gather_into_tensor(Dg, Dm, group=self.group)
+    dist.all_gather_into_tensor(Ig, Im, group=self.group)
+    return Dg[:nq], Ig[:nq]
+
+
+ShardedIndexFlatIP._exchange_sliced = _exchange_sliced_impl
 
 
 def encode_rows(model, batches, n_rows, group=None, to_cpu=False):

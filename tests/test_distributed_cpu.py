@@ -39,7 +39,7 @@ def _merge(Dc, Ic):
     return torch.from_numpy(D), torch.from_numpy(I)
 
 
-def _worker(rank, world, initfile, n, outdir):
+def _worker(rank, world, initfile, n, outdir, exchange="auto"):
     dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
     try:
         rng = np.random.RandomState(7)
@@ -47,7 +47,7 @@ def _worker(rank, world, initfile, n, outdir):
         xb[n // 2 + 3] = xb[5]                       # a cross-shard exact tie
         q = rng.randn(9, 64).astype(np.float32)
         k = 20
-        six = sharded.ShardedIndexFlatIP(64, index_factory=_OracleIndex, merge_fn=_merge)
+        six = sharded.ShardedIndexFlatIP(64, index_factory=_OracleIndex, merge_fn=_merge, exchange=exchange)
         six.add_global(xb)
         assert six.ntotal == n and (six.lo, six.hi) == sharded.shard_range(n, world, rank)
         D, I = six.search(q, k)
@@ -68,12 +68,14 @@ def _worker(rank, world, initfile, n, outdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [101, 7])      # 7 rows < k: -1 padding survives the merge
-def test_sharded_search_world2_gloo(n):
-    world = 2
+# 7 rows < k: -1 padding survives the merge.  "sliced" = the all-to-all exchange by query slices
+# (9 queries over 2 or 3 ranks: ragged last slice, padded rows must not leak into the result)
+@pytest.mark.parametrize("n,world,exchange", [(101, 2, "gather"), (7, 2, "gather"), (101, 2, "sliced"),
+                                              (7, 2, "sliced"), (101, 3, "sliced")])
+def test_sharded_search_gloo(n, world, exchange):
     with tempfile.TemporaryDirectory() as tmp:
         initfile = os.path.join(tmp, "init")
-        mp.spawn(_worker, args=(world, initfile, n, tmp), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, initfile, n, tmp, exchange), nprocs=world, join=True)
         rng = np.random.RandomState(7)
         xb = rng.randn(n, 64).astype(np.float32)
         xb[n // 2 + 3] = xb[5]
