@@ -17,6 +17,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tokens", type=int, default=65536)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--zeros", action="store_true",
+                    help="all-zero operands: the same instruction stream at the clock the chip sustains without data toggling")
     a = ap.parse_args()
     lib = _lib.load()
     M = a.tokens
@@ -29,6 +31,8 @@ def main():
         bias = torch.randn((N,), generator=g, device="cuda")
         R = torch.randn((M, N), generator=g, device="cuda").to(torch.bfloat16)
         C = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+        if a.zeros:
+            A.zero_(); W.zero_(); bias.zero_(); R.zero_()
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
         def run():
@@ -44,7 +48,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
-        print(json.dumps({"gemm": name, "M": M, "N": N, "K": K, "epi": epi, "us": round(ms * 1e3, 1),
+        print(json.dumps({"gemm": name, "M": M, "N": N, "K": K, "epi": epi, "operands": "zeros" if a.zeros else "random", "us": round(ms * 1e3, 1),
                           "TFLOPs": round(2.0 * M * N * K / (ms * 1e-3) / 1e12, 1)}), flush=True)
 
 
