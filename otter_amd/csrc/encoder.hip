@@ -181,6 +181,10 @@ struct AttnArgs {
     const float* kbias; // [B][Lp]: 0 for tokens, -1e30 for padding and for keys in [L, Lp)
     int B, L, Lp, H, heads;
     float scale;
+    // packed (variable-length) batches, bf16 kernel only: sequence b occupies rows
+    // [seq_off[b], seq_off[b] + seq_len[b]) of QKV / CTX, seq_len a multiple of 64 (<= Lp)
+    const int* seq_off = nullptr;
+    const int* seq_len = nullptr;
 };
 
 template <typename T>
@@ -372,24 +376,27 @@ __global__ __launch_bounds__(1024 / QB, QB == 2 ? 2 : 4) void attn_full_kernel(A
     constexpr int NW = 16 / QB;      // waves; each moves PPW of the 16 1-KiB pieces of a 64-key tile
     constexpr int PPW = 16 / NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nt = a.Lp >> 6;                       // 64-key tiles
+    const int b = blockIdx.y;
+    const int Lb = a.seq_len ? __builtin_amdgcn_readfirstlane(a.seq_len[b]) : a.L;       // rows of this sequence
+    const int nt = a.seq_len ? Lb >> 6 : a.Lp >> 6;                                      // 64-key tiles
+    const size_t row0 = a.seq_off ? (size_t)__builtin_amdgcn_readfirstlane(a.seq_off[b]) : (size_t)b * a.L;
     char* sK = smem;                                // [Lp][128 B], chunks swizzled by (row >> 1) & 7
     char* sV = smem + nt * 8192;                    // [Lp][128 B], linear
     float* sB = reinterpret_cast<float*>(smem + 2 * nt * 8192);   // [Lp] additive key bias
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l31 = lane & 31;
-    const int head = blockIdx.x, b = blockIdx.y;
+    const int head = blockIdx.x;
     const int ld = 3 * a.H;
-    const bf16_t* base = (const bf16_t*)a.QKV + (size_t)b * a.L * ld + head * 64;
+    const bf16_t* base = (const bf16_t*)a.QKV + row0 * ld + head * 64;
     const int q0 = wave * 32 * QB;
-    const bool active = q0 < a.L;                   // wave-uniform
+    const bool active = q0 < Lb;                    // wave-uniform
 
     // this lane's two query rows: loads hidden from hipcc (it would drain the DMA queue for them)
     f32x4v qf[QB][4];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        const int qrow = min(q0 + qb * 32 + l31, a.L - 1);
+        const int qrow = min(q0 + qb * 32 + l31, Lb - 1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bf16_t* p = base + (size_t)qrow * ld + (2 * j + h) * 8;
@@ -580,7 +587,7 @@ __global__ __launch_bounds__(1024 / QB, QB == 2 ? 2 : 4) void attn_full_kernel(A
         for (int qb = 0; qb < QB; ++qb) {
             const int q = q0 + qb * 32 + l31;
             const float inv = 1.0f / lrun[qb];
-            bf16_t* dst = (bf16_t*)a.CTX + ((size_t)b * a.L + min(q, a.L - 1)) * a.H + head * 64;
+            bf16_t* dst = (bf16_t*)a.CTX + (row0 + min(q, Lb - 1)) * a.H + head * 64;
 #pragma unroll
             for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -594,7 +601,7 @@ __global__ __launch_bounds__(1024 / QB, QB == 2 ? 2 : 4) void attn_full_kernel(A
                         ov[i] = (__bf16)__uint_as_float(sw[0]);
                         ov[4 + i] = (__bf16)__uint_as_float(sw[1]);
                     }
-                    if (q < a.L)
+                    if (q < Lb)
                         *reinterpret_cast<float4*>(dst + d * 32 + 8 * (rq + h)) = __builtin_bit_cast(float4, ov);
                 }
         }
@@ -622,10 +629,12 @@ int launch_attn_bf16(const AttnArgs& a, hipStream_t st) {
 // RoBERTa position ids: cumsum(ids != pad) * (ids != pad) + pad  (modeling_roberta.py:142-155);
 // BERT: arange(L).  Also writes the additive key-padding bias from input_mask.
 // kbias is [B][Lp], Lp = L rounded up to 64: keys past L are masked like padding tokens.
+// seq_len (optional): rows of sequence b that anything reads = 1 + the last position set in
+// input_mask, part2_mask or part3_mask, rounded up to 64 (the packed path computes only those).
 __global__ void prep_kernel(const long long* ids, const long long* mask, int* pos, float* kbias, int L, int Lp, int pad,
-                            int roberta) {
+                            int roberta, const long long* p2, const long long* p3, int* seq_len) {
     const int b = blockIdx.x, lane = threadIdx.x;  // one wave per sequence
-    int run = 0;
+    int run = 0, last = 0;
     for (int c0 = 0; c0 < Lp; c0 += 64) {
         const int l = c0 + lane;
         const bool in = l < L;
@@ -633,9 +642,28 @@ __global__ void prep_kernel(const long long* ids, const long long* mask, int* po
         const unsigned long long bal = __ballot(tok);
         const int before = __popcll(bal & ((1ull << lane) - 1ull));
         if (in) pos[(size_t)b * L + l] = roberta ? (tok ? run + before + 1 + pad : pad) : l;
-        kbias[(size_t)b * Lp + l] = (in && mask[(size_t)b * L + l] != 0) ? 0.0f : -1e30f;
+        const bool key = in && mask[(size_t)b * L + l] != 0;
+        kbias[(size_t)b * Lp + l] = key ? 0.0f : -1e30f;
         run += __popcll(bal);
+        if (seq_len) {
+            const bool used = key || (in && p2 && p2[(size_t)b * L + l] != 0) || (in && p3 && p3[(size_t)b * L + l] != 0);
+            const unsigned long long ub = __ballot(used);
+            if (ub) last = c0 + 63 - __builtin_clzll(ub);
+        }
     }
+    if (seq_len && lane == 0) seq_len[b] = min(Lp, ((last + 1 + 63) >> 6) << 6);
+}
+
+// exclusive prefix sum of the sequence lengths; info[0] = 256-row tiles in use, info[1] = rows in use
+__global__ void seq_offsets_kernel(const int* seq_len, int B, int* seq_off, int* info) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int acc = 0;
+    for (int b = 0; b < B; ++b) {
+        seq_off[b] = acc;
+        acc += seq_len[b];
+    }
+    info[0] = (acc + 255) >> 8;
+    info[1] = acc;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -649,9 +677,17 @@ template <typename T, int NV>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const long long* ids, const int* pos, const long long* types,
                                                        const float* word, const float* pemb, const float* temb,
                                                        const float* gamma, const float* beta, T* X, int M, int H,
-                                                       int vocab, int npos, int ntype, float eps) {
+                                                       int vocab, int npos, int ntype, float eps,
+                                                       const int* seq_off = nullptr, const int* seq_len = nullptr,
+                                                       int L = 1) {
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (m >= M) return;
+    size_t mo = m;                  // output row: dense, or packed (token l of sequence b -> seq_off[b] + l)
+    if (seq_off) {
+        const int b = m / L, l = m - b * L;
+        if (l >= seq_len[b]) return;
+        mo = (size_t)seq_off[b] + l;
+    }
     long long id = ids[m];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     int p = pos[m];
@@ -682,16 +718,23 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const long long* ids, con
         const int c = i * 256 + lane * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            X[(size_t)m * H + c + e] = from_f<T>((v[4 * i + e] - mean) * rstd * gamma[c + e] + beta[c + e]);
+            X[mo * H + c + e] = from_f<T>((v[4 * i + e] - mean) * rstd * gamma[c + e] + beta[c + e]);
     }
 }
 
-// Y[m] = LN(X[m]); one wave per row
+// Y[m] = LN(X[m]); one wave per row.  With seq_off: X is packed, Y dense (rows nothing reads are skipped)
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_kernel(const T* X, const float* gamma, const float* beta, T* Y, int M, int H,
-                                                 float eps) {
+                                                 float eps, const int* seq_off = nullptr, const int* seq_len = nullptr,
+                                                 int L = 1) {
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (m >= M) return;
+    size_t mi = m;
+    if (seq_off) {
+        const int b = m / L, l = m - b * L;
+        if (l >= seq_len[b]) return;
+        mi = (size_t)seq_off[b] + l;
+    }
     float v[NV * 4];
     float sum = 0.f;
 #pragma unroll
@@ -699,7 +742,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* X, const float* gamma,
         const int c = i * 256 + lane * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[4 * i + e] = to_f<T>(X[(size_t)m * H + c + e]);
+            v[4 * i + e] = to_f<T>(X[mi * H + c + e]);
             sum += v[4 * i + e];
         }
     }
@@ -848,6 +891,7 @@ struct otter_encoder {
     // workspace (grow-only)
     otter::DevBuf X, X1, QKV, CTX, TMP, MID, pos, kbias;
     otter::DevBuf part, stat1, stat2;   // LayerNorm statistics of the fused bf16 path
+    otter::DevBuf seq;                  // packed batches: seq_len[B], seq_off[B], info[2]
     bool ln_fused = false;
     long long ws_rows = 0;
 };
@@ -1026,13 +1070,15 @@ int run_layers_nv(otter_encoder* e, const int64_t* ids, const int64_t* mask, con
     const int Lp = round_up(L, 64);
     int rc;
     hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(64), 0, st, (const long long*)ids, (const long long*)mask,
-                       (int*)e->pos.p, (float*)e->kbias.p, L, Lp, c.pad_token_id, c.position_mode == OTTER_POS_ROBERTA);
+                       (int*)e->pos.p, (float*)e->kbias.p, L, Lp, c.pad_token_id, c.position_mode == OTTER_POS_ROBERTA,
+                       (const long long*)nullptr, (const long long*)nullptr, (int*)nullptr);
     const unsigned rowgrid = (unsigned)((M + 3) / 4);
     hipLaunchKernelGGL((embed_ln_kernel<T, NV>), dim3(rowgrid), dim3(256), 0, st, (const long long*)ids,
                        (const int*)e->pos.p, (const long long*)types, e->w["embeddings.word_embeddings.weight"].d,
                        e->w["embeddings.position_embeddings.weight"].d, e->w["embeddings.token_type_embeddings.weight"].d,
                        e->w["embeddings.LayerNorm.weight"].d, e->w["embeddings.LayerNorm.bias"].d, (T*)e->X.p, (int)M, H,
-                       c.vocab_size, c.max_position_embeddings, c.type_vocab_size, c.layer_norm_eps);
+                       c.vocab_size, c.max_position_embeddings, c.type_vocab_size, c.layer_norm_eps,
+                       (const int*)nullptr, (const int*)nullptr, 1);
     OTTER_HIP_TRY(hipGetLastError());
     for (int li = 0; li < n_layers; ++li) {
         const LayerW& W = e->layers[li];
@@ -1049,11 +1095,11 @@ int run_layers_nv(otter_encoder* e, const int64_t* ids, const int64_t* mask, con
         }
         if ((rc = launch_gemm<T>(EPI_BIAS_RESID, e->CTX.p, W.wo, W.bo, e->X.p, e->TMP.p, M, H, H, e->ncu, st))) return rc;
         hipLaunchKernelGGL((ln_kernel<T, NV>), dim3(rowgrid), dim3(256), 0, st, (const T*)e->TMP.p, W.ln1g, W.ln1b,
-                           (T*)e->X1.p, (int)M, H, c.layer_norm_eps);
+                           (T*)e->X1.p, (int)M, H, c.layer_norm_eps, (const int*)nullptr, (const int*)nullptr, 1);
         if ((rc = launch_gemm<T>(EPI_BIAS_GELU, e->X1.p, W.w1, W.b1, nullptr, e->MID.p, M, I, H, e->ncu, st))) return rc;
         if ((rc = launch_gemm<T>(EPI_BIAS_RESID, e->MID.p, W.w2, W.b2, e->X1.p, e->TMP.p, M, H, I, e->ncu, st))) return rc;
         hipLaunchKernelGGL((ln_kernel<T, NV>), dim3(rowgrid), dim3(256), 0, st, (const T*)e->TMP.p, W.ln2g, W.ln2b,
-                           (T*)e->X.p, (int)M, H, c.layer_norm_eps);
+                           (T*)e->X.p, (int)M, H, c.layer_norm_eps, (const int*)nullptr, (const int*)nullptr, 1);
         OTTER_HIP_TRY(hipGetLastError());
     }
     return OTTER_OK;
@@ -1063,32 +1109,58 @@ int run_layers_nv(otter_encoder* e, const int64_t* ids, const int64_t* mask, con
 // the attention-output and FFN-down GEMMs store the un-normalised sums T1 (X1) and T2 (TMP) plus row
 // statistics; QKV and FFN-up read them through gamma-scaled weights; residuals are normalised on the
 // fly.  Only the last layer's output is materialised (pooling / hidden-state readers need it).
+//
+// Packed batches (pk != null): the rows that nothing reads -- padding past the last position set in
+// input_mask / part2_mask / part3_mask -- are not computed at all.  Sequence b occupies rows
+// [seq_off[b], seq_off[b] + seq_len[b]) of every activation, seq_len a multiple of 64 (attention tiles);
+// the lengths live on the device only (no host synchronisation): the GEMMs read their tile count from
+// seq_info[0], attention its offset and length per sequence, and the final LayerNorm writes the dense
+// [B, L, H] layout the pooling kernels read.  The reference computes every padded position
+// (scripts/encode_corpus.py:139-144 feeds max_length-padded batches); the embeddings are the same.
+struct PackHint {
+    const int64_t* p2;
+    const int64_t* p3;
+};
+
 template <int NV>
 int run_layers_fused(otter_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* types, int B, int L,
-                     int n_layers, hipStream_t st) {
+                     int n_layers, hipStream_t st, const PackHint* pk) {
     typedef bf16_t T;
     const auto& c = e->cfg;
     const long long M = (long long)B * L, M_pad = round_up64(M, 256);
     const int H = c.hidden_size, I = c.intermediate_size;
     const int Lp = round_up(L, 64), P = 4 * (H / 256);
     int rc;
+    int *seq_len = nullptr, *seq_off = nullptr, *seq_info = nullptr;
+    if (pk) {
+        if ((rc = e->seq.reserve((size_t)(2 * B + 2) * sizeof(int)))) return rc;
+        seq_len = (int*)e->seq.p;
+        seq_off = seq_len + B;
+        seq_info = seq_off + B;
+    }
     hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(64), 0, st, (const long long*)ids, (const long long*)mask,
-                       (int*)e->pos.p, (float*)e->kbias.p, L, Lp, c.pad_token_id, c.position_mode == OTTER_POS_ROBERTA);
+                       (int*)e->pos.p, (float*)e->kbias.p, L, Lp, c.pad_token_id, c.position_mode == OTTER_POS_ROBERTA,
+                       (const long long*)(pk ? pk->p2 : nullptr), (const long long*)(pk ? pk->p3 : nullptr), seq_len);
+    if (pk) hipLaunchKernelGGL(seq_offsets_kernel, dim3(1), dim3(64), 0, st, (const int*)seq_len, B, seq_off, seq_info);
     const unsigned rowgrid = (unsigned)((M + 3) / 4);
     hipLaunchKernelGGL((embed_ln_kernel<T, NV>), dim3(rowgrid), dim3(256), 0, st, (const long long*)ids,
                        (const int*)e->pos.p, (const long long*)types, e->w["embeddings.word_embeddings.weight"].d,
                        e->w["embeddings.position_embeddings.weight"].d, e->w["embeddings.token_type_embeddings.weight"].d,
                        e->w["embeddings.LayerNorm.weight"].d, e->w["embeddings.LayerNorm.bias"].d, (T*)e->X.p, (int)M, H,
-                       c.vocab_size, c.max_position_embeddings, c.type_vocab_size, c.layer_norm_eps);
+                       c.vocab_size, c.max_position_embeddings, c.type_vocab_size, c.layer_norm_eps,
+                       (const int*)seq_off, (const int*)seq_len, L);
     OTTER_HIP_TRY(hipGetLastError());
     for (int li = 0; li < n_layers; ++li) {
         const LayerW& W = e->layers[li];
         GemmLN ln;
         if (li == 0) {
-            if ((rc = launch_gemm_bf16(GEMM_EPI_BIAS, e->X.p, W.wqkv, W.bqkv, nullptr, e->QKV.p, M_pad, 3 * H, H, e->ncu, st)))
+            ln.tiles_m_dev = seq_info;
+            if ((rc = launch_gemm_bf16_ln(GEMM_EPI_BIAS, e->X.p, W.wqkv, W.bqkv, nullptr, e->QKV.p, M_pad, 3 * H, H, ln, e->ncu,
+                                          st)))
                 return rc;
         } else {
             ln = GemmLN();
+            ln.tiles_m_dev = seq_info;
             ln.mode = 1; ln.stat = e->stat2.p; ln.v0 = W.sqkv; ln.v1 = W.cqkv;
             if ((rc = launch_gemm_bf16_ln(GEMM_EPI_BIAS, e->TMP.p, W.wqkv_f, nullptr, nullptr, e->QKV.p, M_pad, 3 * H, H, ln,
                                           e->ncu, st)))
@@ -1098,6 +1170,7 @@ int run_layers_fused(otter_encoder* e, const int64_t* ids, const int64_t* mask, 
         a.QKV = e->QKV.p; a.CTX = e->CTX.p; a.kbias = (const float*)e->kbias.p;
         a.B = B; a.L = L; a.Lp = Lp; a.H = H; a.heads = c.num_attention_heads;
         a.scale = 1.0f / sqrtf((float)(H / c.num_attention_heads));
+        a.seq_off = seq_off; a.seq_len = seq_len;
         if (L <= 512) {
             if ((rc = launch_attn_bf16(a, st))) return rc;
         } else {
@@ -1106,6 +1179,7 @@ int run_layers_fused(otter_encoder* e, const int64_t* ids, const int64_t* mask, 
         }
         // T1 = x + ctx Wo^T + bo, x = the embedding output (layer 0) or LN2 of the previous layer's T2
         ln = GemmLN();
+        ln.tiles_m_dev = seq_info;
         ln.part = e->part.p;
         if (li == 0) {
             ln.mode = 1;
@@ -1119,6 +1193,7 @@ int run_layers_fused(otter_encoder* e, const int64_t* ids, const int64_t* mask, 
         if ((rc = launch_ln_stats(e->part.p, P, M_pad, H, c.layer_norm_eps, e->stat1.p, st))) return rc;
         // MID = gelu(LN1(T1) W1^T + b1)
         ln = GemmLN();
+        ln.tiles_m_dev = seq_info;
         ln.mode = 1; ln.stat = e->stat1.p; ln.v0 = W.s1; ln.v1 = W.c1;
         if ((rc = launch_gemm_bf16_ln(GEMM_EPI_BIAS_GELU, e->X1.p, W.w1_f, nullptr, nullptr, e->MID.p, M_pad, I, H, ln, e->ncu,
                                       st)))
@@ -1126,6 +1201,7 @@ int run_layers_fused(otter_encoder* e, const int64_t* ids, const int64_t* mask, 
         // T2 = LN1(T1) + MID W2^T + b2   (T2 overwrites the previous layer's T2: its last reader was this
         // layer's attention-output GEMM)
         ln = GemmLN();
+        ln.tiles_m_dev = seq_info;
         ln.mode = 2; ln.stat = e->stat1.p; ln.v0 = W.ln1g; ln.v1 = W.ln1b; ln.part = e->part.p;
         if ((rc = launch_gemm_bf16_ln(GEMM_EPI_BIAS_RESID, e->MID.p, W.w2, W.b2, e->X1.p, e->TMP.p, M_pad, H, I, ln, e->ncu,
                                       st)))
@@ -1134,22 +1210,29 @@ int run_layers_fused(otter_encoder* e, const int64_t* ids, const int64_t* mask, 
             if ((rc = launch_ln_stats(e->part.p, P, M_pad, H, c.layer_norm_eps, e->stat2.p, st))) return rc;
         } else {
             hipLaunchKernelGGL((ln_kernel<T, NV>), dim3(rowgrid), dim3(256), 0, st, (const T*)e->TMP.p, W.ln2g, W.ln2b,
-                               (T*)e->X.p, (int)M, H, c.layer_norm_eps);
+                               (T*)e->X.p, (int)M, H, c.layer_norm_eps, (const int*)seq_off, (const int*)seq_len, L);
             OTTER_HIP_TRY(hipGetLastError());
         }
     }
+    if (pk && n_layers == 0) return set_err(OTTER_EINVAL, "packed path needs at least one layer");
     return OTTER_OK;
 }
 
 template <typename T>
 int run_layers(otter_encoder* e, const int64_t* ids, const int64_t* mask, const int64_t* types, int B, int L,
-               int n_layers, hipStream_t st) {
+               int n_layers, hipStream_t st, const PackHint* pk = nullptr) {
     if (sizeof(T) == 2 && e->ln_fused) {
+        // packing pays when whole 64-row tiles can be dropped; the 'max' pooling of an EMPTY part mask reads
+        // padded positions (tb_retriever.py:50-52), so that method keeps the dense layout
+        const char* nopack = getenv("OTTER_NO_PACK");
+        if (pk && (L % 64 != 0 || L < 128 || L > 512 || n_layers < 1 || e->cfg.part_pooling == OTTER_POOL_MAX ||
+                   (nopack && nopack[0] == '1')))
+            pk = nullptr;
         switch (e->cfg.hidden_size / 256) {
-            case 1: return run_layers_fused<1>(e, ids, mask, types, B, L, n_layers, st);
-            case 2: return run_layers_fused<2>(e, ids, mask, types, B, L, n_layers, st);
-            case 3: return run_layers_fused<3>(e, ids, mask, types, B, L, n_layers, st);
-            case 4: return run_layers_fused<4>(e, ids, mask, types, B, L, n_layers, st);
+            case 1: return run_layers_fused<1>(e, ids, mask, types, B, L, n_layers, st, pk);
+            case 2: return run_layers_fused<2>(e, ids, mask, types, B, L, n_layers, st, pk);
+            case 3: return run_layers_fused<3>(e, ids, mask, types, B, L, n_layers, st, pk);
+            case 4: return run_layers_fused<4>(e, ids, mask, types, B, L, n_layers, st, pk);
         }
     }
     switch (e->cfg.hidden_size / 256) {
@@ -1306,7 +1389,8 @@ int otter_encoder_forward(otter_encoder* e, const int64_t* input_ids, const int6
     hipStream_t st = (hipStream_t)stream;
     const int nl = e->cfg.num_hidden_layers;
     if (e->dtype == OTTER_BF16) {
-        if ((rc = run_layers<bf16_t>(e, input_ids, input_mask, type_ids, B, L, nl, st))) return rc;
+        const PackHint pk = {part2_mask, part3_mask};
+        if ((rc = run_layers<bf16_t>(e, input_ids, input_mask, type_ids, B, L, nl, st, &pk))) return rc;
         return pool_out<bf16_t>(e, part2_mask, part3_mask, B, L, out, st);
     }
     if ((rc = run_layers<float>(e, input_ids, input_mask, type_ids, B, L, nl, st))) return rc;
@@ -1390,7 +1474,7 @@ void otter_encoder_destroy(otter_encoder* e) {
     for (void* p : e->owned) (void)hipFree(p);
     e->X.release(); e->X1.release(); e->QKV.release(); e->CTX.release();
     e->TMP.release(); e->MID.release(); e->pos.release(); e->kbias.release();
-    e->part.release(); e->stat1.release(); e->stat2.release();
+    e->part.release(); e->stat1.release(); e->stat2.release(); e->seq.release();
     delete e;
 }
 

@@ -64,6 +64,7 @@ struct PPArgs {
     const float* v1;    // [N] c_n (EPI 0/1) or beta  (EPI 2, LN 2)
     float2* part;       // EPI 2: [4 * tiles_n][M_pad] (sum, sum of squares) over 64 columns of what was stored
     long long M_pad;
+    const int* tiles_m_dev;   // optional: number of 256-row tiles actually in use (<= tiles_m), read on the device
     unsigned long long* dbg;   // GEMM_DIAG builds only
 };
 
@@ -140,14 +141,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
     // (column-major inside a patch), so that the workgroups of an XCD, which take consecutive
     // list positions, work on ~8 A tiles x ~4 W tiles at a time instead of 32 x 1.
     // Any schedule is correct; this one is for L2 hits only.
+    // packed (variable-length) batches: the row count is known on the device only
+    const int tiles_m = a.tiles_m_dev ? min(__builtin_amdgcn_readfirstlane(*a.tiles_m_dev), a.tiles_m) : a.tiles_m;
     const bool xmode = (nblk & 7) == 0;
     const int wpx = xmode ? nblk >> 3 : nblk;                  // list stride of this workgroup
     const int idx = xmode ? bid >> 3 : bid;                    // first list position
-    int tm0 = 0, n_tm = a.tiles_m;
+    int tm0 = 0, n_tm = tiles_m;
     if (xmode) {
         const int x = bid & 7;
-        tm0 = (int)(((long long)x * a.tiles_m) >> 3);
-        n_tm = (int)(((long long)(x + 1) * a.tiles_m) >> 3) - tm0;
+        tm0 = (int)(((long long)x * tiles_m) >> 3);
+        n_tm = (int)(((long long)(x + 1) * tiles_m) >> 3) - tm0;
     }
     const int list_len = n_tm * a.tiles_n;
     const int n_my = idx < list_len ? (list_len - idx + wpx - 1) / wpx : 0;
@@ -602,6 +605,7 @@ int launch_gemm_bf16_ln(int epi, const void* A, const void* W, const float* bias
     a.v1 = ln.v1;
     a.part = (float2*)ln.part;
     a.M_pad = M_pad;
+    a.tiles_m_dev = ln.tiles_m_dev;
     void (*kern)(PPArgs) = nullptr;
     int nvec = 1;
     if (epi == GEMM_EPI_BIAS) {

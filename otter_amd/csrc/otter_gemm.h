@@ -25,6 +25,9 @@ struct GemmLN {
     const float* v0 = nullptr;    // [N]
     const float* v1 = nullptr;    // [N]
     void* part = nullptr;         // float2 [4 * N / 256][M_pad]
+    // independent of `mode`: device int, the number of 256-row tiles in use (<= M_pad / 256); the
+    // packed variable-length encoder path knows its row count on the device only
+    const int* tiles_m_dev = nullptr;
 };
 int launch_gemm_bf16_ln(int epi, const void* A, const void* W, const float* bias, const void* R, void* C,
                         long long M_pad, int N, int K, const GemmLN& ln, int ncu, hipStream_t st);

@@ -121,3 +121,46 @@ def test_bf16_hidden_states_track_fp32_path(B, L):
         err = np.abs(got - ref)
         assert np.isfinite(got).all()
         assert err.max() < 0.15 and err.mean() < 0.012, (n, float(err.max()), float(err.mean()))
+
+
+@pytest.mark.parametrize("family,pooling,L", [("roberta", "first", 512), ("roberta", "mean", 256), ("bert", "first", 128),
+                                              ("roberta", "cls1", 384)])
+def test_packed_batches_equal_the_dense_layout(family, pooling, L):
+    # bf16 path, ragged batch (one full-length row, one 1-token row, one row whose part3 mask is empty and one
+    # whose part mask reaches past input_mask): the packed layout skips the padded rows, the dense layout
+    # (OTTER_NO_PACK=1) computes them like the reference; the embeddings must agree to fp32 rounding of the
+    # pooling (every per-row operation is the same instruction sequence on the same data in both layouts)
+    import os
+    three = pooling != "cls1"
+    cfg = R.make_config(family, layers=2, vocab_size=2000, three_cat=three, part_pooling=pooling if three else "first")
+    B = 6
+    batch = R.make_batch(cfg, B, L, 5 + L)
+    lens = [L, 1, 70, 64, L - 1, 130]
+    for b, n in enumerate(lens):
+        batch["input_mask"][b, :] = 0
+        batch["input_mask"][b, :n] = 1
+        batch["input_ids"][b, n:] = cfg["pad_token_id"]
+        for k in ("part2_mask", "part3_mask"):
+            if k in batch:
+                batch[k][b, n:] = 0
+    if three:
+        batch["part3_mask"][2, :] = 0                   # empty part: 'first' falls back to row 0, 'mean' gives NaN
+        batch["part2_mask"][3, 100] = 1                 # a part position past the last input_mask position
+    dev = {k: v.cuda() for k, v in batch.items()}
+    model = _model(cfg, 3, dtype="bf16")
+    packed = model(dev)["embed"].cpu().numpy()
+    os.environ["OTTER_NO_PACK"] = "1"
+    try:
+        dense = model(dev)["embed"].cpu().numpy()
+    finally:
+        del os.environ["OTTER_NO_PACK"]
+    assert packed.shape == dense.shape
+    assert (np.isnan(packed) == np.isnan(dense)).all()
+    ok = ~np.isnan(dense)
+    assert ok.any()
+    np.testing.assert_allclose(packed[ok], dense[ok], rtol=1e-5, atol=1e-5)
+    # and a second, shorter batch through the same (grown) workspace
+    dev2 = {k: v[:2].contiguous() for k, v in dev.items()}
+    again = model(dev2)["embed"].cpu().numpy()
+    ok2 = ~np.isnan(dense[:2])
+    np.testing.assert_allclose(again[ok2], dense[:2][ok2], rtol=1e-5, atol=1e-5)
