@@ -141,6 +141,37 @@ def encode_leg(rank, world, local_rank, dist, steps, warmup, batch, cpu_ref):
                         "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
                         "kernel": "whole forward (12 x [qkv gemm, attention, o gemm, ln, ffn1 gemm, ffn2 gemm, ln])",
                         "device_ms_per_batch": dev_ms, "algorithmic_flops_per_block": flops_block}}
+    # SURVEY.md §8d ragged variant, reported separately: token counts ~U[64, 512] padded to 512 the way the
+    # reference's tokenizer call pads (retrieval/data/tr_dataset.py:139-141); the packed layout skips those rows
+    rs2 = np.random.RandomState(778 + rank)
+    ids2 = np.full((batch, L), cfg["pad_token_id"], np.int64)
+    m2 = np.zeros((batch, L), np.int64)
+    q2 = np.zeros((batch, L), np.int64)
+    q3 = np.zeros((batch, L), np.int64)
+    for i in range(batch):
+        n = int(rs2.randint(64, L + 1))
+        a_end = max(2, n // 4)
+        ids2[i, :n] = rs2.randint(3, cfg["vocab_size"], size=n)
+        ids2[i, 0] = 0
+        ids2[i, a_end] = 2
+        ids2[i, a_end + 1] = 2
+        ids2[i, n - 1] = 2
+        m2[i, :n] = 1
+        q2[i, 1:a_end] = 1
+        q3[i, a_end + 2:n - 1] = 1
+    rb = {"input_ids": torch.from_numpy(ids2).cuda(), "input_mask": torch.from_numpy(m2).cuda(),
+          "part2_mask": torch.from_numpy(q2).cuda(), "part3_mask": torch.from_numpy(q3).cuda()}
+    model(rb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rout = model(rb)["embed"]
+    torch.cuda.synchronize()
+    rdt = (time.perf_counter() - t0) / steps
+    res["ragged_variant"] = {"value": batch / rdt, "unit": "blocks/s (this rank)", "mean_tokens": float(m2.sum()) / batch,
+                             "padded_to": L, "ms_per_batch": rdt * 1e3,
+                             "finite": bool(torch.isfinite(rout).all().item()),
+                             "note": "lengths ~U[64,512]; rows past the last masked-in position are not computed"}
     if cpu_ref:
         # fp32 recall-style check of the bf16 path on 2 blocks + CPU baseline timing (oracle restatement)
         ref = R.EncoderRef(cfg, sd)
