@@ -83,6 +83,18 @@ int otter_index_search(otter_index* ix, const void* q, int64_t nq, int k,
                        float* D, int64_t* I, int io_is_device, void* stream);
 
 /* index.ntotal / index.d */
+/* Search restricted to per-query row subsets.  Replaces the reference's per-question throw-away index
+ * (retrieval/eval_ottqa_retrieval_tfidffilter.py:530-546: faiss.IndexFlatIP(d); index.add(qid2emb[qid]);
+ * index.search(q[idx:idx+1], beam_size)) with one batched call on the resident corpus.
+ * ids: int64 [nq, m], row ids of this index (insertion order + id_base), lists shorter than m padded with -1;
+ * any other value is an error (OTTER_EINVAL).  D float32 [nq, k], I int64 [nq, k]: the k best listed rows per
+ * query by (score descending, id ascending), I = the row id as listed (not the position in the list);
+ * fewer than k valid ids leave I = -1, D = -FLT_MAX.  Scores are bit-identical to otter_index_search's for
+ * the same rows.  fp32 indexes only.  q, ids, D, I are all host or all device pointers (io_is_device);
+ * the call synchronises the stream (id validation). */
+int otter_index_search_subset(otter_index* index, const void* q, int64_t nq, int k, const int64_t* ids, int m,
+                              float* D, int64_t* I, int io_is_device, void* stream);
+
 int64_t otter_index_ntotal(const otter_index* ix);
 int     otter_index_d(const otter_index* ix);
 

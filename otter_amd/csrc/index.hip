@@ -757,6 +757,27 @@ __global__ void max_norm_kernel(const float* norm2, long long rows, u32* out) {
 // cores fed exactly like scan_kernel (16-byte fragments, k order 0,4,1,5,2,6,3,7 per 8), the
 // query in every column, so every output is bit for bit the score scan_kernel computes.
 // Writes composites (exact key, row) into out[s][q][slot] with s = candidate / k.
+// one wave per query: valid ids of the list to the front (order kept), -1 behind them; ids that are neither
+// -1 nor rows of this index are counted in *bad
+__global__ void subset_ids_kernel(const long long* __restrict__ in, long long* __restrict__ out, int m,
+                                  long long id_base, long long n, u32* bad) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const long long* src = in + (size_t)q * m;
+    long long* dst = out + (size_t)q * m;
+    int kept = 0, nbad = 0;
+    for (int c0 = 0; c0 < m; c0 += 64) {
+        const int i = c0 + lane;
+        const long long id = i < m ? src[i] : -1ll;
+        const bool ok = id >= id_base && id - id_base < n;
+        if (i < m && !ok && id != -1ll) ++nbad;
+        const unsigned long long bal = __ballot(ok);
+        if (ok) dst[kept + __popcll(bal & ((1ull << lane) - 1ull))] = id;
+        kept += __popcll(bal);
+    }
+    for (int i = kept + lane; i < m; i += 64) dst[i] = -1ll;
+    if (nbad) atomicAdd(bad, (u32)nbad);
+}
+
 struct RescoreArgs {
     const float* X;        // [n][ld]
     const float* Q;        // [nq_pad][ld] (zero padded)
@@ -1719,6 +1740,95 @@ int otter_index_search(otter_index* ix, const void* q, int64_t nq, int k, float*
         OTTER_HIP_TRY(hipMemcpyAsync(D, Dd, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
         OTTER_HIP_TRY(hipMemcpyAsync(I, Id, (size_t)nq * k * sizeof(long long), hipMemcpyDeviceToHost, st));
         OTTER_HIP_TRY(hipStreamSynchronize(st));
+    }
+    return OTTER_OK;
+}
+
+// Search restricted to per-query id subsets: the reference builds a throw-away
+// faiss.IndexFlatIP over the TF-IDF-filtered blocks of every question and searches it with that one
+// question (retrieval/eval_ottqa_retrieval_tfidffilter.py:530-546).  Here the corpus stays resident: the
+// listed rows are gathered and scored with the exact kernel's fp32 chain (rescore_kernel), then selected
+// by the merge kernel; scores are bit-identical to those search() returns for the same rows.
+int otter_index_search_subset(otter_index* ix, const void* q, int64_t nq, int k, const int64_t* ids, int m, float* D,
+                              int64_t* I, int io_is_device, void* stream) {
+    if (!ix) return set_err(OTTER_EINVAL, "search_subset: index is NULL");
+    if (ix->dtype != OTTER_F32) return set_err(OTTER_ENOTIMPL, "search_subset: fp32 index only");
+    if (nq < 0) return set_err(OTTER_EINVAL, "search_subset: nq=%lld < 0", (long long)nq);
+    if (k < 1 || k > OTTER_MAX_K) return set_err(OTTER_EINVAL, "search_subset: k=%d outside [1, %d]", k, OTTER_MAX_K);
+    if (m < 1 || m > (1 << 20)) return set_err(OTTER_EINVAL, "search_subset: m=%d outside [1, 2^20]", m);
+    if (nq == 0) return OTTER_OK;
+    if (!q || !D || !I || !ids) return set_err(OTTER_EINVAL, "search_subset: q, ids, D and I must be non-NULL");
+    DeviceGuard g(ix->device);
+    if (!g.ok) return set_err(OTTER_EHIP, "search_subset: hipSetDevice(%d) failed", ix->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    const int S2 = (m + k - 1) / k;
+    // chunk the queries so that the candidate lists stay below ~256 MB
+    const long long per_q = (long long)S2 * k * (long long)sizeof(u64) + (long long)m * 8;
+    const long long chunk = std::max<long long>(1, std::min<long long>(QCHUNK, (256ll << 20) / per_q));
+    if ((rc = ix->flags.reserve(2 * sizeof(u32)))) return rc;
+    for (long long q0 = 0; q0 < nq; q0 += chunk) {
+        const long long c = std::min<long long>(chunk, nq - q0);
+        const long long c_pad = round_up64(c, S16_BQ);
+        if ((rc = ix->qpad.reserve((size_t)c_pad * ix->ld * sizeof(float)))) return rc;
+        if ((rc = ix->cI.reserve((size_t)c * m * sizeof(long long)))) return rc;
+        if ((rc = ix->rs.reserve((size_t)S2 * c_pad * k * sizeof(u64)))) return rc;
+        if ((rc = ix->rscnt.reserve((size_t)S2 * c_pad * sizeof(u32)))) return rc;
+        if ((rc = ix->io_D.reserve((size_t)c * k * sizeof(float)))) return rc;
+        if ((rc = ix->io_I.reserve((size_t)c * k * sizeof(long long)))) return rc;
+        const float* qd = (const float*)q + (size_t)q0 * ix->d;
+        const long long* idd = (const long long*)ids + (size_t)q0 * m;
+        float* Dd = D + (size_t)q0 * k;
+        long long* Id = (long long*)I + (size_t)q0 * k;
+        if (!io_is_device) {
+            if ((rc = ix->io_q.reserve((size_t)c * ix->d * sizeof(float)))) return rc;
+            if ((rc = ix->fb_I.reserve((size_t)c * m * sizeof(long long)))) return rc;
+            OTTER_HIP_TRY(hipMemcpyAsync(ix->io_q.p, qd, (size_t)c * ix->d * sizeof(float), hipMemcpyHostToDevice, st));
+            OTTER_HIP_TRY(hipMemcpyAsync(ix->fb_I.p, idd, (size_t)c * m * sizeof(long long), hipMemcpyHostToDevice, st));
+            qd = (const float*)ix->io_q.p;
+            idd = (const long long*)ix->fb_I.p;
+            Dd = (float*)ix->io_D.p;
+            Id = (long long*)ix->io_I.p;
+        }
+        u32* flag = (u32*)ix->flags.p;
+        OTTER_HIP_TRY(hipMemsetAsync(flag, 0, sizeof(u32), st));
+        // valid ids to the front of every list (the re-scoring kernel counts on that), bad ids flagged
+        hipLaunchKernelGGL(subset_ids_kernel, dim3((unsigned)c), dim3(64), 0, st, idd, (long long*)ix->cI.p, m,
+                           (long long)ix->id_base, ix->n, flag);
+        {
+            const long long total = c_pad * ix->ld;
+            hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256),
+                               0, st, qd, (float*)ix->qpad.p, c, c_pad, ix->d, ix->ld);
+        }
+        OTTER_HIP_TRY(hipGetLastError());
+        u32 bad = 0;
+        OTTER_HIP_TRY(hipMemcpyAsync(&bad, flag, sizeof(u32), hipMemcpyDeviceToHost, st));
+        OTTER_HIP_TRY(hipStreamSynchronize(st));
+        if (bad)
+            return set_err(OTTER_EINVAL, "search_subset: %u ids outside [-1] U [%lld, %lld)", bad, (long long)ix->id_base,
+                           (long long)(ix->id_base + ix->n));
+        RescoreArgs ra;
+        ra.X = ix->x;
+        ra.Q = (const float*)ix->qpad.p;
+        ra.Ic = (const long long*)ix->cI.p;
+        ra.out = (u64*)ix->rs.p;
+        ra.out_cnt = (u32*)ix->rscnt.p;
+        ra.id_base = ix->id_base;
+        ra.ld = ix->ld;
+        ra.kc = m;
+        ra.k = k;
+        ra.nq_pad = (int)c_pad;
+        hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)c), dim3(256), 0, st, ra);
+        OTTER_HIP_TRY(hipGetLastError());
+        if ((rc = run_merge(ix, (const u64*)ix->rs.p, (const u32*)ix->rscnt.p, k, S2, c, c_pad, k, true, Dd, Id, nullptr,
+                            nullptr, nullptr, nullptr, nullptr, st)))
+            return rc;
+        if (!io_is_device) {
+            OTTER_HIP_TRY(hipMemcpyAsync(D + (size_t)q0 * k, Dd, (size_t)c * k * sizeof(float), hipMemcpyDeviceToHost, st));
+            OTTER_HIP_TRY(hipMemcpyAsync(I + (size_t)q0 * k, Id, (size_t)c * k * sizeof(long long), hipMemcpyDeviceToHost,
+                                         st));
+            OTTER_HIP_TRY(hipStreamSynchronize(st));
+        }
     }
     return OTTER_OK;
 }

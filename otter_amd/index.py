@@ -120,6 +120,75 @@ class IndexFlatIP:
                                                 _stream_ptr(self.device)), "otter_index_search")
         return D, I
 
+    def search_subsets(self, q, k, subsets, return_positions=False):
+        """Per-query search restricted to row subsets: what the reference does by building a throw-away
+        faiss.IndexFlatIP over each question's TF-IDF-filtered blocks
+        (retrieval/eval_ottqa_retrieval_tfidffilter.py:530-546), as one batched call on the resident corpus.
+
+        subsets: a sequence of nq 1-D integer arrays of row ids (ragged), or an int64 [nq, m] array / CUDA
+        tensor padded with -1.  Returns (D, I): I holds row ids, or -- return_positions=True, the
+        reference's convention (its small index numbers the subset's rows 0..len-1) -- positions in the
+        subset (the first position of a repeated id)."""
+        k = int(k)
+        if k < 1 or k > _lib.OTTER_MAX_K:
+            raise ValueError("search_subsets: k=%d outside [1, %d]" % (k, _lib.OTTER_MAX_K))
+        on_dev = _is_torch(q) and q.is_cuda
+        if _is_torch(subsets):
+            ids = subsets.to(torch.int64)
+        elif isinstance(subsets, np.ndarray) and subsets.ndim == 2:
+            ids = np.ascontiguousarray(subsets, dtype=np.int64)
+        else:
+            lens = [len(s) for s in subsets]
+            ids = np.full((len(lens), max(1, max(lens) if lens else 1)), -1, dtype=np.int64)
+            for i, s_ in enumerate(subsets):
+                ids[i, :lens[i]] = np.asarray(s_, dtype=np.int64)
+        nq = q.shape[0]
+        if ids.ndim != 2 or ids.shape[0] != nq or ids.shape[1] < 1:
+            raise ValueError("search_subsets: need one id list per query, got %r for %d queries" % (tuple(ids.shape), nq))
+        m = int(ids.shape[1])
+        if on_dev:
+            if q.dim() != 2 or q.shape[1] != self.d or q.device.index != self.device:
+                raise ValueError("search_subsets: expected [nq, %d] on device %d" % (self.d, self.device))
+            q = q.to(torch.float32).contiguous()
+            ids_d = (ids if _is_torch(ids) else torch.from_numpy(ids)).to(q.device).contiguous()
+            D = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+            if nq:
+                _lib.check(self._lib.otter_index_search_subset(
+                    self._h, ctypes.c_void_p(q.data_ptr()), nq, k, ctypes.c_void_p(ids_d.data_ptr()), m,
+                    ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()), 1, _stream_ptr(self.device)),
+                    "otter_index_search_subset")
+            if return_positions:
+                eq = I.unsqueeze(2) == ids_d.unsqueeze(1)                       # [nq, k, m]
+                pos = torch.where(eq.any(2) & (I >= 0), eq.to(torch.int8).argmax(2), torch.full_like(I, -1))
+                return D, pos
+            return D, I
+        if _is_torch(q):
+            q = q.detach().numpy()
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self.d:
+            raise ValueError("search_subsets: expected [nq, %d] float32, got %r" % (self.d, q.shape))
+        if _is_torch(ids):
+            ids = ids.cpu().numpy()
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        if nq:
+            _lib.check(self._lib.otter_index_search_subset(
+                self._h, ctypes.c_void_p(q.ctypes.data), nq, k, ctypes.c_void_p(ids.ctypes.data), m,
+                ctypes.c_void_p(D.ctypes.data), ctypes.c_void_p(I.ctypes.data), 0, _stream_ptr(self.device)),
+                "otter_index_search_subset")
+        if return_positions:
+            pos = np.full_like(I, -1)
+            for i in range(nq):
+                first = {}
+                for j, v in enumerate(ids[i]):
+                    if v >= 0 and int(v) not in first:
+                        first[int(v)] = j
+                pos[i] = [first.get(int(v), -1) if v >= 0 else -1 for v in I[i]]
+            return D, pos
+        return D, I
+
     @property
     def last_fallback(self):
         """Queries of the last search() that the coarse bf16 pass could not prove and the exact kernel re-did."""

@@ -173,3 +173,80 @@ def test_errors_are_loud():
         ix.search(np.zeros((3, 768), np.float32), 4096)
     with pytest.raises(ValueError):
         IndexFlatIP(0)
+
+
+@pytest.mark.parametrize("n,d,nq,k,mmax", [(5000, 768, 9, 100, 700), (3000, 2304, 4, 10, 64), (70000, 128, 33, 100, 3000),
+                                            (500, 64, 5, 50, 20)])
+def test_subset_search_matches_a_per_query_index(n, d, nq, k, mmax):
+    # the reference builds IndexFlatIP over each question's filtered blocks and searches it with that one
+    # question (eval_ottqa_retrieval_tfidffilter.py:530-546): the oracle does literally that, the library does
+    # one batched call; ids exact, scores bit-exact (same fp32 chain as the full search)
+    from otter_amd.index import IndexFlatIP
+    rng = np.random.RandomState(n + d + nq + k)
+    xb, q = _mk(n, d, nq, seed=n + k)
+    xb[17] = xb[3]                                               # an exact tie inside some subsets
+    subsets = []
+    for i in range(nq):
+        m = int(rng.randint(1, mmax + 1)) if i else mmax          # ragged; query 0 has the longest list
+        s = np.sort(rng.choice(n, size=m, replace=False))
+        if i == 1:
+            s = np.unique(np.concatenate([s, [3, 17]]))[:mmax]
+        subsets.append(s)
+    ix = IndexFlatIP(d)
+    ix.add(xb)
+    D, I = ix.search_subsets(q, k, subsets)
+    D2, P = ix.search_subsets(q, k, subsets, return_positions=True)
+    Df, If = ix.search(q, min(k, n))
+    ix.close()
+    assert D.dtype == np.float32 and I.dtype == np.int64 and D.shape == (nq, k)
+    for i in range(nq):
+        s = subsets[i]
+        kk = min(k, len(s))
+        Dr, Ir = flat_ip.search_c(xb[s], q[i:i + 1], k, mode=flat_ip.MODE_GPU_ORDER)
+        np.testing.assert_array_equal(P[i], Ir[0])              # the reference's convention: positions in the subset
+        np.testing.assert_array_equal(I[i, :kk], s[Ir[0, :kk]])
+        assert (I[i, kk:] == -1).all()
+        np.testing.assert_array_equal(D[i].view(np.uint32), Dr[0].view(np.uint32))
+        # a row that is in the subset AND in the full search's top k carries the same score there
+        common = np.intersect1d(I[i, :kk], If[i])
+        for r in common[:5]:
+            assert D[i][list(I[i]).index(r)] == Df[i][list(If[i]).index(r)]
+    np.testing.assert_array_equal(D, D2)
+
+
+def test_subset_search_device_io_id_base_and_errors():
+    import torch
+    from otter_amd.index import IndexFlatIP
+    xb, q = _mk(2000, 96, 6, seed=3)
+    ix = IndexFlatIP(96, id_base=1000)
+    ix.add(xb)
+    ids = np.full((6, 40), -1, np.int64)
+    rng = np.random.RandomState(0)
+    for i in range(6):
+        m = int(rng.randint(5, 41))
+        ids[i, :m] = 1000 + np.sort(rng.choice(2000, size=m, replace=False))
+    ids[2, [1, 4]] = -1                                           # holes inside a list are skipped
+    Dh, Ih = ix.search_subsets(q, 8, ids)
+    Dd, Id = ix.search_subsets(torch.from_numpy(q).cuda(), 8, torch.from_numpy(ids).cuda())
+    np.testing.assert_array_equal(Ih, Id.cpu().numpy())
+    np.testing.assert_array_equal(Dh.view(np.uint32), Dd.cpu().numpy().view(np.uint32))
+    for i in range(6):
+        s = ids[i][ids[i] >= 0] - 1000
+        Dr, Ir = flat_ip.search_c(xb[s], q[i:i + 1], 8, mode=flat_ip.MODE_GPU_ORDER)
+        kk = min(8, len(s))
+        np.testing.assert_array_equal(Ih[i, :kk], 1000 + s[Ir[0, :kk]])
+    bad = ids.copy()
+    bad[0, 0] = 5                                                 # below id_base
+    with pytest.raises(ValueError):
+        ix.search_subsets(q, 8, bad)
+    bad[0, 0] = 3000                                              # past the last row
+    with pytest.raises(ValueError):
+        ix.search_subsets(q, 8, bad)
+    with pytest.raises(ValueError):
+        ix.search_subsets(q, 8, ids[:3])
+    ix.close()
+    ib = IndexFlatIP(96, dtype="bf16")
+    ib.add(xb)
+    with pytest.raises(NotImplementedError):
+        ib.search_subsets(q, 8, np.zeros((6, 4), np.int64))
+    ib.close()
