@@ -138,3 +138,21 @@ def test_id2doc_and_embedding_formats(tmp_path, feats):
     os.remove(tmp_path / "sh" / "corpus.shard00001.json")
     with pytest.raises(ValueError):
         F.open_embedding_shards(str(tmp_path / "sh" / "corpus"))
+
+
+def test_whitening_matches_the_reference_golden():
+    """otter_amd.whitening against outputs of the reference's own functions (oracle/gen_whitening_golden.py).
+    The SVD fixes the kernel's columns only up to sign, so the comparison is on what the search sees: the
+    Gram matrix q' x'^T (invariant to those signs), plus the defining property (unit covariance)."""
+    import numpy as np
+    from otter_amd import whitening as W
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "whitening.npz"))
+    w1, w2 = W.whitening(g["e1"], g["e2"])
+    assert w1.dtype == np.float32 and w2.dtype == np.float32 and w1.shape == g["w1"].shape
+    np.testing.assert_allclose(w2 @ w1.T, g["w2"] @ g["w1"].T, rtol=2e-3, atol=2e-3)
+    kernel, bias = W.compute_kernel_bias(np.concatenate([g["e1"], g["e2"]], 0))
+    np.testing.assert_allclose(bias, g["bias"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(kernel @ kernel.T, g["kernel"] @ g["kernel"].T, rtol=1e-6, atol=1e-8)
+    allv = np.concatenate([w1, w2], 0).astype(np.float64)
+    np.testing.assert_allclose(np.cov(allv.T), np.eye(allv.shape[1]), atol=5e-3)
+    assert W.transform_and_normalize(g["e1"]) is g["e1"] or np.array_equal(W.transform_and_normalize(g["e1"]), g["e1"])
