@@ -1298,7 +1298,9 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
         // MFMA-bound batches on a large corpus: coarse pass on the bf16 matrix cores + exact re-scoring
         static const char* no_split_env = getenv("OTTER_NO_SPLIT");
         const int kc = k + std::max(28, k / 8);
-        if (!no_split_env && !ix->no_split && nq >= 192 && ix->n >= 65536 && kc <= S16_MAX_K) {
+        static const char* split_min_env = getenv("OTTER_SPLIT_MIN_NQ");   // tuning runs only
+        static const int split_min = split_min_env ? atoi(split_min_env) : 65;   // above the 64-query tile of the exact kernel
+        if (!no_split_env && !ix->no_split && nq >= split_min && ix->n >= 65536 && kc <= S16_MAX_K) {
             const int rs = ensure_split_planes(ix, st);
             if (rs < 0) return rs;
             if (rs == 0) return search_chunk_split(ix, qd, nq, k, kc, D, I, st);
