@@ -139,7 +139,7 @@ def encode_leg(rank, world, local_rank, dist, steps, warmup, batch, cpu_ref):
            "finite": bool(torch.isfinite(out).all().item()),
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
-                        "kernel": "whole forward (12 x [qkv gemm, attention, o gemm, ln, ffn1 gemm, ffn2 gemm, ln])",
+                        "kernel": "whole forward (12 x [qkv gemm, attention, o gemm, ffn1 gemm, ffn2 gemm], LayerNorms folded into the gemm epilogues)",
                         "device_ms_per_batch": dev_ms, "algorithmic_flops_per_block": flops_block}}
     # SURVEY.md §8d ragged variant, reported separately: token counts ~U[64, 512] padded to 512 the way the
     # reference's tokenizer call pads (retrieval/data/tr_dataset.py:139-141); the packed layout skips those rows
