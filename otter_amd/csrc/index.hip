@@ -442,14 +442,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct Scan16Args {
-    const char* X;      // corpus, bf16: [cap_rows][ldk]
-    const char* Q;      // queries, bf16: [nq_pad][ldk]
+    const char* X;      // corpus, bf16, tile-blocked plane of cap_rows x ldk elements (plane_index)
+    const char* Q;      // queries, bf16, tile-blocked plane of nq_pad x ldk elements
     u64* cand;          // [S][nq_pad][CAP]
     u32* cnt;           // [S][nq_pad]
     long long n;
     int ldk;            // row length in bf16 elements: ld (MODE 0) or 2 * ld (MODE 1), multiple of 64
     int nq, nq_pad, k;
     int qtiles, strips, total_tiles;
+    u32* sync;          // [strips] zeroed per launch, or null: soft tile barrier among the workgroups of a strip
 };
 
 constexpr int S16_HT = 16384, S16_BUF = 4 * S16_HT;
@@ -498,12 +499,12 @@ __global__ __launch_bounds__(512, 2) void scan16_kernel(Scan16Args a) {
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         const int arow = (r & 63) + 128 * (r >> 6);
         const int wrow = 64 * (r >> 5) + (r & 31);
-        voffA[i2] = ((u32)arow * (u32)a.ldk + (u32)c * 8u) * 2u;
-        voffB[i2] = ((u32)wrow * (u32)a.ldk + (u32)c * 8u) * 2u;
+        voffA[i2] = (u32)arow * 128u + (u32)c * 16u;          // inside one 32 KiB K-slab block (plane_index)
+        voffB[i2] = (u32)wrow * 128u + (u32)c * 16u;
     }
     const u32 lds0 = (u32)(uintptr_t)(AS3 char*)smem;
     const u32 dma_dst = (u32)(wave * 2) * 1024u;
-    const char* gQ = a.Q + (size_t)q0 * a.ldk * 2;
+    const char* gQ = a.Q + ((size_t)(u32)(qt * KT) << 15);
     int is_stage = 0, is_t = 0, is_tile = t0;
     bool is_valid = false;
     const char* is_gA = gQ;
@@ -513,8 +514,8 @@ __global__ __launch_bounds__(512, 2) void scan16_kernel(Scan16Args a) {
         if (kind == 0) {
             is_valid = is_stage < total_stages;
             if (is_valid) {
-                is_gA = gQ + (size_t)is_t * 128;
-                is_gW = a.X + (size_t)is_tile * S16_BM * a.ldk * 2 + (size_t)is_t * 128;
+                is_gA = gQ + ((size_t)(u32)is_t << 15);
+                is_gW = a.X + ((size_t)(u32)(is_tile * KT + is_t) << 15);     // block index < 2^31 (host check)
                 is_lds = lds0 + (u32)(is_stage & 1) * S16_BUF + dma_dst;
                 ++is_stage;
                 if (++is_t == KT) { is_t = 0; ++is_tile; }
@@ -528,11 +529,11 @@ __global__ __launch_bounds__(512, 2) void scan16_kernel(Scan16Args a) {
                 dma16s(is_gW, voffB[0], is_lds + S16_BF);
                 dma16s(is_gW, voffB[1], is_lds + S16_BF + 1024);
             } else if (kind == 2) {
-                const char* b = is_gW + (size_t)32 * a.ldk * 2;
+                const char* b = is_gW + 32 * 128;
                 dma16s(b, voffB[0], is_lds + S16_BS);
                 dma16s(b, voffB[1], is_lds + S16_BS + 1024);
             } else {
-                const char* b = is_gA + (size_t)64 * a.ldk * 2;
+                const char* b = is_gA + 64 * 128;
                 dma16s(b, voffA[0], is_lds + S16_AS);
                 dma16s(b, voffA[1], is_lds + S16_AS + 1024);
             }
@@ -688,6 +689,21 @@ __global__ __launch_bounds__(512, 2) void scan16_kernel(Scan16Args a) {
                 wg_barrier();
                 if (g == 0) {
                     epilogue(c_tile);
+                    // Soft tile barrier: the qtiles workgroups of a strip stream the same corpus tiles and
+                    // only hit in L2 while they stay within a few K-steps of each other.  Arrive, then wait
+                    // -- at most ~2 us, never unbounded: co-residency of the partners is likely, not
+                    // guaranteed -- until every partner has finished this tile.
+                    if (a.sync && wave == 0) {
+                        u32* ctr = a.sync + strip;
+                        if (lane == 0) (void)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const u32 target = (u32)a.qtiles * (u32)(c_tile - t0 + 1);
+                        for (int it = 0; it < 6; ++it) {
+                            const u32 v = __builtin_amdgcn_readfirstlane(
+                                __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            if (v >= target) break;
+                            __builtin_amdgcn_s_sleep(4);
+                        }
+                    }
                     wg_barrier();        // group 0 waits for group 1: every wave is past its epilogue
                 }
                 if (__builtin_amdgcn_readfirstlane(*sFlag)) compact_pass(false);   // same barriers for all waves
@@ -704,23 +720,36 @@ __global__ __launch_bounds__(512, 2) void scan16_kernel(Scan16Args a) {
 }
 
 // fp32 rows [rows][d] -> bf16 rows [rows_pad][ld] (MODE 0), zero padded
+// Plane layout of everything scan16_kernel streams (corpus and query planes alike): tile-blocked.
+// Element e (0 .. ldk-1) of row R lives at
+//     (((R >> 8) * (ldk / 64) + (e >> 6)) * 256 + (R & 255)) * 64 + (e & 63)
+// i.e. the 64-element K-slab of a 256-row tile is ONE contiguous 32 KiB block (256 rows x 128 B): the
+// LDS-DMA of a half-tile reads 16 KiB of consecutive addresses instead of 128 rows x 128 B at a 3 KiB
+// stride (HBM pages, L2 channel spread).  Buffers hold whole 256-row tiles.
+__device__ __forceinline__ size_t plane_index(long long R, int e, int ldk) {
+    return ((size_t)((R >> 8) * (ldk >> 6) + (e >> 6)) * 256 + (size_t)(R & 255)) * 64 + (size_t)(e & 63);
+}
+
+// `dst` is the plane base, `row0` the first destination row (incremental adds)
 __global__ void to_bf16_rows_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long long rows,
-                                    long long rows_pad, int d, int ld) {
+                                    long long rows_pad, int d, int ld, long long row0) {
     const long long total = rows_pad * ld;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const long long r = i / ld;
         const int c = (int)(i - r * ld);
         const float v = (r < rows && c < d) ? src[r * d + c] : 0.0f;
-        dst[i] = __builtin_bit_cast(unsigned short, (__bf16)v);
+        dst[plane_index(row0 + r, c, ld)] = __builtin_bit_cast(unsigned short, (__bf16)v);
     }
 }
 
-// fp32 rows [rows][sld] (first d valid) -> split rows [rows_pad][2 ld]: per 32 values of k, 32 hi then 32 lo
-// (MODE 1); optionally the squared norm of every row (norm2[rows_pad]) for the error bound.
+// fp32 rows [rows][sld] (first d valid) -> split rows of 2 ld elements: per 32 values of k, 32 hi then 32 lo
+// (MODE 1), in the tile-blocked plane layout from row `row0` of the plane `dst` on; optionally the squared
+// norm of every row (norm2[rows_pad], indexed from 0) for the error bound.
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, long long sld,
                                                          unsigned short* __restrict__ dst, long long rows,
-                                                         long long rows_pad, int d, int ld, float* norm2) {
+                                                         long long rows_pad, int d, int ld, float* norm2,
+                                                         long long row0) {
     const int lane = threadIdx.x & 63;
     const long long w0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
     const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
@@ -730,7 +759,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
             const float v = (r < rows && c < d) ? src[r * sld + c] : 0.0f;
             const __bf16 hi = (__bf16)v;
             const __bf16 lo = (__bf16)(v - (float)hi);
-            unsigned short* o = dst + r * 2 * ld + (c >> 5) * 64 + (c & 31);
+            unsigned short* o = dst + plane_index(row0 + r, (c >> 5) * 64 + (c & 31), 2 * ld);   // lo: +32, same slab
             o[0] = __builtin_bit_cast(unsigned short, hi);
             o[32] = __builtin_bit_cast(unsigned short, lo);
             ss += v * v;
@@ -753,10 +782,6 @@ __global__ void max_norm_kernel(const float* norm2, long long rows, u32* out) {
     if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
-// Exact scores of the coarse candidates: one wave per (query, 32 candidates), the fp32 matrix
-// cores fed exactly like scan_kernel (16-byte fragments, k order 0,4,1,5,2,6,3,7 per 8), the
-// query in every column, so every output is bit for bit the score scan_kernel computes.
-// Writes composites (exact key, row) into out[s][q][slot] with s = candidate / k.
 // one wave per query: valid ids of the list to the front (order kept), -1 behind them; ids that are neither
 // -1 nor rows of this index are counted in *bad
 __global__ void subset_ids_kernel(const long long* __restrict__ in, long long* __restrict__ out, int m,
@@ -778,6 +803,10 @@ __global__ void subset_ids_kernel(const long long* __restrict__ in, long long* _
     if (nbad) atomicAdd(bad, (u32)nbad);
 }
 
+// Exact scores of the coarse candidates: one wave per (query, 32 candidates), the fp32 matrix
+// cores fed exactly like scan_kernel (16-byte fragments, k order 0,4,1,5,2,6,3,7 per 8), the
+// query in every column, so every output is bit for bit the score scan_kernel computes.
+// Writes composites (exact key, row) into out[s][q][slot] with s = candidate / k.
 struct RescoreArgs {
     const float* X;        // [n][ld]
     const float* Q;        // [nq_pad][ld] (zero padded)
@@ -1182,7 +1211,7 @@ struct otter_index {
     long long xs_rows = 0, xs_cap = 0;
     bool xs_failed = false, no_split = false;
     long long last_fallback = 0;    // queries of the last split search that went to the exact kernel
-    otter::DevBuf qs, qnorm2, cD, cI, rs, rscnt, flags, fb_q, fb_D, fb_I;
+    otter::DevBuf qs, qnorm2, cD, cI, rs, rscnt, flags, fb_q, fb_D, fb_I, tsync;
     otter::DevBuf qpad, cand, cnt, lvl[2], lvlcnt[2], smp, smpcnt, thr0, io_q, io_D, io_I;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
@@ -1214,7 +1243,8 @@ int index_reserve_rows(otter_index* ix, long long need_rows, hipStream_t st) {
     // rows past n are read by whole-tile loads (and multiplied by real queries): keep them finite
     OTTER_HIP_TRY(hipMemsetAsync(nx, 0, (size_t)want * ix->ld * esz, st));
     if (ix->n > 0)
-        OTTER_HIP_TRY(hipMemcpyAsync(nx, old, (size_t)ix->n * ix->ld * esz, hipMemcpyDeviceToDevice, st));
+        // (whole tiles: the bf16 plane is tile-blocked, the tail rows of the last tile are zero)
+        OTTER_HIP_TRY(hipMemcpyAsync(nx, old, (size_t)round_up64(ix->n, 256) * ix->ld * esz, hipMemcpyDeviceToDevice, st));
     OTTER_HIP_TRY(hipStreamSynchronize(st));
     if (old) OTTER_HIP_TRY(hipFree(old));
     if (ix->dtype == OTTER_BF16) ix->x16 = (unsigned short*)nx;
@@ -1471,6 +1501,13 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
     sa.qtiles = qtiles;
     sa.strips = strips;
     sa.total_tiles = total_tiles;
+    sa.sync = nullptr;
+    static const char* nosync = getenv("OTTER_NO_TILE_SYNC");
+    if (qtiles > 1 && !(nosync && nosync[0] == '1')) {
+        if ((rc = ix->tsync.reserve((size_t)strips * sizeof(u32)))) return rc;
+        OTTER_HIP_TRY(hipMemsetAsync(ix->tsync.p, 0, (size_t)strips * sizeof(u32), st));
+        sa.sync = (u32*)ix->tsync.p;
+    }
     if ((rc = launch_scan16_timed(ix, cfg, sa, qtiles * strips, st))) return rc;
     return run_merge(ix, (const u64*)ix->cand.p, (const u32*)ix->cnt.p, cfg.cap, strips, nq, nq_pad, kk, true, Dc, Ic,
                      nullptr, nullptr, nullptr, nullptr, nullptr, st);
@@ -1484,7 +1521,7 @@ int search_chunk_bf16(otter_index* ix, const float* qd, long long nq, int k, flo
     {
         const long long total = nq_pad * ix->ld;
         hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256),
-                           0, st, qd, (unsigned short*)ix->qs.p, nq, nq_pad, ix->d, ix->ld);
+                           0, st, qd, (unsigned short*)ix->qs.p, nq, nq_pad, ix->d, ix->ld, 0ll);
         OTTER_HIP_TRY(hipGetLastError());
     }
     return scan16_and_merge<0>(ix, ix->x16, ix->ld, nq, k, D, I, st);
@@ -1522,8 +1559,7 @@ int ensure_split_planes(otter_index* ix, hipStream_t st) {
         const long long lo = ix->xs_rows, rows = ix->n - lo;
         hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)std::min<long long>((rows + 3) / 4, 16384)), dim3(256), 0,
                            st, ix->x + (size_t)lo * ix->ld, (long long)ix->ld,
-                           (unsigned short*)ix->xs.p + (size_t)lo * 2 * ix->ld, rows, rows, ix->ld, ix->ld,
-                           (float*)ix->xnorm2.p + lo);
+                           (unsigned short*)ix->xs.p, rows, rows, ix->ld, ix->ld, (float*)ix->xnorm2.p + lo, lo);
         hipLaunchKernelGGL(max_norm_kernel, dim3((unsigned)std::min<long long>((rows + 255) / 256, 1024)), dim3(256), 0,
                            st, (const float*)ix->xnorm2.p + lo, rows, (u32*)ix->xnmax.p);
         OTTER_HIP_TRY(hipGetLastError());
@@ -1552,7 +1588,8 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, in
     if ((rc = ix->rscnt.reserve((size_t)S2 * nq_pad * sizeof(u32)))) return rc;
     if ((rc = ix->flags.reserve((size_t)(nq + 1) * sizeof(u32)))) return rc;
     hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)std::min<long long>((nq_pad + 3) / 4, 16384)), dim3(256), 0, st,
-                       qd, (long long)ix->d, (unsigned short*)ix->qs.p, nq, nq_pad, ix->d, ix->ld, (float*)ix->qnorm2.p);
+                       qd, (long long)ix->d, (unsigned short*)ix->qs.p, nq, nq_pad, ix->d, ix->ld, (float*)ix->qnorm2.p,
+                       0ll);
     {
         const long long total = nq_pad * ix->ld;
         hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0,
@@ -1679,7 +1716,7 @@ int otter_index_add(otter_index* ix, const void* x, int64_t n, int x_is_device, 
             }
             const long long total = c * ix->ld;
             hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 8192)),
-                               dim3(256), 0, st, src, ix->x16 + (size_t)(ix->n + lo) * ix->ld, c, c, ix->d, ix->ld);
+                               dim3(256), 0, st, src, ix->x16, c, c, ix->d, ix->ld, (long long)(ix->n + lo));
             OTTER_HIP_TRY(hipGetLastError());
             if (!x_is_device) OTTER_HIP_TRY(hipStreamSynchronize(st));   // the staging slab is reused
         }
@@ -1889,7 +1926,7 @@ void otter_index_destroy(otter_index* ix) {
     if (ix->x) (void)hipFree(ix->x);
     if (ix->x16) (void)hipFree(ix->x16);
     for (otter::DevBuf* b : {&ix->xs, &ix->xnorm2, &ix->xnmax, &ix->qs, &ix->qnorm2, &ix->cD, &ix->cI, &ix->rs,
-                             &ix->rscnt, &ix->flags, &ix->fb_q, &ix->fb_D, &ix->fb_I})
+                             &ix->rscnt, &ix->flags, &ix->fb_q, &ix->fb_D, &ix->fb_I, &ix->tsync})
         b->release();
     ix->qpad.release();
     ix->cand.release();
