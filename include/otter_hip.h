@@ -144,6 +144,12 @@ typedef struct otter_encoder otter_encoder;
 #define OTTER_POOL_MAX   2
 #define OTTER_POOL_CLS   3
 #define OTTER_POOL_FIRST 4
+/* att_self_pool of the ...ThreeCatAtt encoders (retrieval/models/tb_retriever.py:510-523, selected by
+ * scripts/encode_corpus.py:50-66 when part_pooling starts with 'att'): softmax over positions of
+ * Linear(H,1)(h) + (1 - mask) * -1e6, weighted sum of h.  Needs the tensors self_proj_tab.{weight,bias}
+ * (part 2) and self_proj_psg.{weight,bias} (part 3).  'att_self_multihead' needs a module the reference
+ * does not ship and is not built. */
+#define OTTER_POOL_ATT_SELF 5
 
 /* position-id conventions of the HF embedding layer */
 #define OTTER_POS_BERT    0   /* position = arange(L)                                   */

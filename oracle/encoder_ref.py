@@ -81,6 +81,12 @@ def make_state_dict(cfg, seed):
     sd["project.0.weight"] = nrm((H, H), 0.04)
     sd["project.0.bias"] = nrm((H,), 0.02)
     ln("project.1", sd)
+    if str(cfg.get("part_pooling", ""))[:3] == "att":
+        # ...ThreeCatAtt: Linear(H, 1) per side (tb_retriever.py:419-421); drawn last, so every other
+        # configuration keeps its stream
+        for side in ("tab", "psg"):
+            sd["self_proj_%s.weight" % side] = nrm((1, H), 0.3)
+            sd["self_proj_%s.bias" % side] = nrm((1,), 0.1)
     return sd
 
 
@@ -124,6 +130,15 @@ def make_batch(cfg, B, L, seed, ragged=True, question=False):
     if not rob:
         batch["input_type_ids"] = torch.from_numpy(tt)
     return batch
+
+
+def att_self_pool(hidden, mask, weight, bias):
+    """One side of tb_retriever.py:510-523: softmax over positions of Linear(H,1)(h) + (1 - m) * -1e6,
+    weighted sum of h (`.squeeze()` of the B = 1 case not reproduced, as in pooling_masked_part below)."""
+    m = mask.to(hidden.dtype).unsqueeze(2)
+    logits = torch.nn.functional.linear(hidden, weight, bias)
+    att = torch.softmax(logits + (1 - m) * -1e6, dim=1)
+    return torch.sum(att * hidden, dim=1)
 
 
 def pooling_masked_part(hidden, mask, method="mean"):
@@ -214,6 +229,10 @@ class EncoderRef:
                                                    w["project.1.bias"], c["layer_norm_eps"])
         if not c["three_cat"]:
             return {"embed": part1}
+        if c["part_pooling"] == "att_self_pool":
+            part2 = att_self_pool(h, batch["part2_mask"], w["self_proj_tab.weight"], w["self_proj_tab.bias"])
+            part3 = att_self_pool(h, batch["part3_mask"], w["self_proj_psg.weight"], w["self_proj_psg.bias"])
+            return {"embed": torch.cat([part1, part2, part3], dim=1)}
         part2 = pooling_masked_part(h, batch["part2_mask"], c["part_pooling"])
         part3 = pooling_masked_part(h, batch["part3_mask"], c["part_pooling"])
         return {"embed": torch.cat([part1, part2, part3], dim=1)}

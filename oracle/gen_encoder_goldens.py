@@ -67,16 +67,24 @@ def _hf_model_dir(cfg, sd, tmp, tag):
     return d, hcfg
 
 
+ONLY = [t for t in os.environ.get("OTTER_GOLDEN_ONLY", "").split(",") if t]   # regenerate just these tags
+
+
 def run_case(tag, cfg, wseed, batch, tmp, klass="threecat", encode_table=True, probes=None, dup_b1=False):
+    if ONLY and tag not in ONLY:
+        return
     from retrieval.models.retriever import RobertaSingleEncoder, SingleEncoder
     from retrieval.models.tb_retriever import RobertaSingleEncoderThreeCatPool, SingleEncoderThreeCatPool
+    from retrieval.models.tb_retriever import RobertaSingleEncoderThreeCatAtt, SingleEncoderThreeCatAtt
     from retrieval.utils.utils import load_saved
     sd = R.make_state_dict(cfg, wseed)
     mdir, hcfg = _hf_model_dir(cfg, sd, tmp, tag)
     args = SimpleNamespace(model_name=mdir, shared_encoder=True, no_proj=cfg["no_proj"],
                            part_pooling=cfg["part_pooling"], encode_table=encode_table)
     rob = cfg["family"] == "roberta"
-    if klass == "threecat":
+    if klass == "threecat" and str(cfg["part_pooling"])[:3] == "att":
+        model = (RobertaSingleEncoderThreeCatAtt if rob else SingleEncoderThreeCatAtt)(hcfg, args)
+    elif klass == "threecat":
         model = (RobertaSingleEncoderThreeCatPool if rob else SingleEncoderThreeCatPool)(hcfg, args)
     else:
         model = (RobertaSingleEncoder if rob else SingleEncoder)(hcfg, args)
@@ -166,6 +174,13 @@ def main():
         run_case("bert2_first", cfg, 14, R.make_batch(cfg, 4, 96, 27), tmp)
         cfg = R.make_config("bert", layers=2, vocab_size=2000, part_pooling="mean", no_proj=False)
         run_case("bert2_mean_proj", cfg, 14, R.make_batch(cfg, 4, 96, 27), tmp)
+        # attention pooling of the ...ThreeCatAtt encoders (scripts/encode_corpus.py:50-66), one row with an empty part
+        cfg = R.make_config("roberta", part_pooling="att_self_pool", **small)
+        b = R.make_batch(cfg, 4, 96, 28)
+        b["part3_mask"][2] = 0
+        run_case("rob2_att_self_pool", cfg, 15, b, tmp)
+        cfg = R.make_config("bert", layers=2, vocab_size=2000, part_pooling="att_self_pool", no_proj=False)
+        run_case("bert2_att_self_pool_proj", cfg, 16, R.make_batch(cfg, 3, 80, 29), tmp)
         # full roberta-base shape: 12 layers, vocab 50265, L = 512, ragged
         cfg = R.make_config("roberta")
         run_case("rob12_first_L512", cfg, 99, R.make_batch(cfg, 2, 512, 777), tmp,

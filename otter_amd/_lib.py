@@ -16,7 +16,7 @@ OTTER_F32, OTTER_BF16, OTTER_F16, OTTER_I64 = 0, 1, 2, 3
 OTTER_MAX_K = 2048
 MERGE_MAX = 8192
 
-POOL = {"mean": 0, "sum": 1, "max": 2, "cls": 3, "first": 4}
+POOL = {"mean": 0, "sum": 1, "max": 2, "cls": 3, "first": 4, "att_self_pool": 5}
 POS_BERT, POS_ROBERTA = 0, 1
 
 c_i64 = ctypes.c_int64

@@ -808,6 +808,51 @@ __global__ __launch_bounds__(256) void pool_kernel(const T* X, const long long* 
     (void)sCnt;
 }
 
+// att_self_pool (tb_retriever.py:510-523): out = sum_l softmax_l(w.h[l] + b + (1 - m[l]) * -1e6) * h[l]
+// grid (B, 2): part 1 = table side (self_proj_tab, part2_mask), part 2 = passage side (self_proj_psg, part3_mask)
+template <typename T>
+__global__ __launch_bounds__(256) void att_pool_kernel(const T* X, const long long* mask2, const long long* mask3,
+                                                       const float* w_tab, const float* b_tab, const float* w_psg,
+                                                       const float* b_psg, float* out, int L, int H, int D) {
+    extern __shared__ float sl[];   // [L] logits -> weights, [8] reduce
+    float* red = sl + L;
+    const int b = blockIdx.x, part = blockIdx.y + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* hb = X + (size_t)b * L * H;
+    const long long* mk = (part == 1 ? mask2 : mask3) + (size_t)b * L;
+    const float* w = part == 1 ? w_tab : w_psg;
+    const float bias = part == 1 ? b_tab[0] : b_psg[0];
+    for (int l = wave; l < L; l += 4) {
+        float acc = 0.f;
+        for (int c = lane; c < H; c += 64) acc = fmaf(to_f<T>(hb[(size_t)l * H + c]), w[c], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) sl[l] = acc + bias + (1.0f - (float)mk[l]) * -1e6f;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int l = tid; l < L; l += 256) mx = fmaxf(mx, sl[l]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int l = tid; l < L; l += 256) {
+        const float e = expf(sl[l] - mx);
+        sl[l] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    float* ob = out + (size_t)b * D + (size_t)part * H;
+    for (int c = tid; c < H; c += 256) {
+        float acc = 0.f;
+        for (int l = 0; l < L; ++l) acc = fmaf(sl[l] * inv, to_f<T>(hb[(size_t)l * H + c]), acc);
+        ob[c] = acc;
+    }
+}
+
 // part1 = LN(Linear(h[:,0]))  (project = Sequential(Linear, LayerNorm), tb_retriever.py:162-163)
 template <typename T>
 __global__ __launch_bounds__(256) void proj_ln_kernel(const T* X, const float* W, const float* bias,
@@ -914,6 +959,8 @@ int expected_shape(const otter_encoder_cfg& c, const std::string& name, std::vec
     if (name == "embeddings.token_type_embeddings.weight") { *shp = {c.type_vocab_size, H}; return 0; }
     if (name == "embeddings.LayerNorm.weight" || name == "embeddings.LayerNorm.bias") { *shp = {H}; return 0; }
     if (name == "project.0.weight") { *shp = {H, H}; return 0; }
+    if (name == "self_proj_tab.weight" || name == "self_proj_psg.weight") { *shp = {1, H}; return 0; }
+    if (name == "self_proj_tab.bias" || name == "self_proj_psg.bias") { *shp = {1}; return 0; }
     if (name == "project.0.bias" || name == "project.1.weight" || name == "project.1.bias") { *shp = {H}; return 0; }
     if (name.rfind("encoder.layer.", 0) == 0) {
         const char* p = name.c_str() + 14;
@@ -1226,7 +1273,7 @@ int run_layers(otter_encoder* e, const int64_t* ids, const int64_t* mask, const 
         // padded positions (tb_retriever.py:50-52), so that method keeps the dense layout
         const char* nopack = getenv("OTTER_NO_PACK");
         if (pk && (L % 64 != 0 || L < 128 || L > 512 || n_layers < 1 || e->cfg.part_pooling == OTTER_POOL_MAX ||
-                   (nopack && nopack[0] == '1')))
+                   e->cfg.part_pooling == OTTER_POOL_ATT_SELF || (nopack && nopack[0] == '1')))
             pk = nullptr;
         switch (e->cfg.hidden_size / 256) {
             case 1: return run_layers_fused<1>(e, ids, mask, types, B, L, n_layers, st, pk);
@@ -1255,7 +1302,14 @@ int pool_out(otter_encoder* e, const int64_t* p2, const int64_t* p3, int B, int 
                            e->w["project.1.bias"].d, out, L, H, D, c.layer_norm_eps);
         part_lo = 1;
     }
-    const int parts = (c.three_cat ? 3 : 1) - part_lo;
+    int parts = (c.three_cat ? 3 : 1) - part_lo;
+    if (c.three_cat && c.part_pooling == OTTER_POOL_ATT_SELF) {
+        hipLaunchKernelGGL(att_pool_kernel<T>, dim3(B, 2), dim3(256), (size_t)(L + 8) * sizeof(float), st, (const T*)e->X.p,
+                           (const long long*)p2, (const long long*)p3, e->w["self_proj_tab.weight"].d,
+                           e->w["self_proj_tab.bias"].d, e->w["self_proj_psg.weight"].d, e->w["self_proj_psg.bias"].d, out,
+                           L, H, D);
+        parts = 1 - part_lo;             // part 0 (h[:,0]) below unless the projection wrote it
+    }
     if (parts > 0)
         hipLaunchKernelGGL(pool_kernel<T>, dim3(B, parts), dim3(256), 0, st, (const T*)e->X.p, (const long long*)p2,
                            (const long long*)p3, out, L, H, D, c.part_pooling, part_lo);
@@ -1295,7 +1349,7 @@ int otter_encoder_create(const otter_encoder_cfg* cfg, int device, otter_encoder
                        c.intermediate_size);
     if (c.num_hidden_layers < 1 || c.vocab_size < 1 || c.max_position_embeddings < 1 || c.type_vocab_size < 1)
         return set_err(OTTER_EINVAL, "encoder_create: bad layer/vocab/position/type sizes");
-    if (c.part_pooling < OTTER_POOL_MEAN || c.part_pooling > OTTER_POOL_FIRST)
+    if (c.part_pooling < OTTER_POOL_MEAN || c.part_pooling > OTTER_POOL_ATT_SELF)
         return set_err(OTTER_EINVAL, "encoder_create: unknown pooling %d", c.part_pooling);
     if (c.position_mode != OTTER_POS_BERT && c.position_mode != OTTER_POS_ROBERTA)
         return set_err(OTTER_EINVAL, "encoder_create: unknown position_mode %d", c.position_mode);
@@ -1361,6 +1415,9 @@ int otter_encoder_finalize(otter_encoder* e, int compute_dtype) {
         for (const char* n : per_layer) need.push_back("encoder.layer." + std::to_string(li) + "." + n);
     if (!e->cfg.no_proj)
         for (const char* n : {"project.0.weight", "project.0.bias", "project.1.weight", "project.1.bias"}) need.push_back(n);
+    if (e->cfg.three_cat && e->cfg.part_pooling == OTTER_POOL_ATT_SELF)
+        for (const char* n : {"self_proj_tab.weight", "self_proj_tab.bias", "self_proj_psg.weight", "self_proj_psg.bias"})
+            need.push_back(n);
     for (const auto& n : need)
         if (e->w.find(n) == e->w.end()) return set_err(OTTER_ESTATE, "finalize: tensor '%s' was never set", n.c_str());
     DeviceGuard g(e->device);

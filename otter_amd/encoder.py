@@ -77,6 +77,7 @@ class _EncoderBase:
 
     three_cat = True
     roberta = False
+    att = False            # ...ThreeCatAtt: attention pooling with its own self_proj_tab / self_proj_psg tensors
 
     def __init__(self, config, args, device=None, dtype=None):
         self.config = config
@@ -85,8 +86,11 @@ class _EncoderBase:
         self.no_proj = bool(getattr(args, "no_proj", True))
         self.part_pooling = getattr(args, "part_pooling", "first") if self.three_cat else "cls"
         self.encode_table = bool(getattr(args, "encode_table", True))
-        if self.part_pooling[:3] == "att":
-            raise NotImplementedError("attention pooling (…ThreeCatAtt classes) is outside the built path")
+        if self.part_pooling[:3] == "att" and not (self.att and self.part_pooling == "att_self_pool"):
+            # tb_retriever.py:433-434; 'att_self_multihead' needs attention.SelfAttention, which the reference does not ship
+            raise NotImplementedError("part pooling only support att_self_pool (…ThreeCatAtt classes)")
+        if self.att and self.part_pooling != "att_self_pool":
+            raise NotImplementedError("part pooling only support att_self_pool, att_self_multihead is not built")
         if dtype is None:
             dtype = "bf16" if getattr(args, "fp16", False) else "fp32"
         if dtype not in ("fp32", "bf16"):
@@ -134,6 +138,8 @@ class _EncoderBase:
         if not self.shared_encoder:
             keys += ["encoder_q." + k for k in self._expected_keys()]
         keys += ["project.0.weight", "project.0.bias", "project.1.weight", "project.1.bias"]
+        if self.att:
+            keys += ["self_proj_tab.weight", "self_proj_tab.bias", "self_proj_psg.weight", "self_proj_psg.bias"]
         return set(keys)
 
     def state_dict(self):
@@ -316,6 +322,16 @@ class SingleEncoderThreeCatPool(_EncoderBase):
 class RobertaSingleEncoderThreeCatPool(_EncoderBase):
     """retrieval/models/tb_retriever.py:250-261 — the reference's default encoder."""
     three_cat, roberta = True, True
+
+
+class SingleEncoderThreeCatAtt(_EncoderBase):
+    """retrieval/models/tb_retriever.py:404-523 with part_pooling='att_self_pool' (BERT family)."""
+    three_cat, roberta, att = True, False, True
+
+
+class RobertaSingleEncoderThreeCatAtt(_EncoderBase):
+    """retrieval/models/tb_retriever.py:555-560 — chosen by scripts/encode_corpus.py:50-52 for 'att*' pooling."""
+    three_cat, roberta, att = True, True, True
 
 
 class SingleEncoder(_EncoderBase):

@@ -19,10 +19,12 @@ CLASSES = {}
 
 def _model(cfg, seed, dtype="fp32", encode_table=True):
     from otter_amd import encoder as E
+    att = cfg["three_cat"] and str(cfg["part_pooling"])[:3] == "att"
     if cfg["family"] == "roberta":
-        cls = E.RobertaSingleEncoderThreeCatPool if cfg["three_cat"] else E.RobertaSingleEncoder
+        cls = (E.RobertaSingleEncoderThreeCatAtt if att else E.RobertaSingleEncoderThreeCatPool) if cfg["three_cat"] \
+            else E.RobertaSingleEncoder
     else:
-        cls = E.SingleEncoderThreeCatPool if cfg["three_cat"] else E.SingleEncoder
+        cls = (E.SingleEncoderThreeCatAtt if att else E.SingleEncoderThreeCatPool) if cfg["three_cat"] else E.SingleEncoder
     m = cls(U.hf_like_config(cfg), U.ref_args(cfg, encode_table=encode_table), dtype=dtype)
     m.load_state_dict(U.state_dict_for(cfg, seed), strict=False)
     return m.to("cuda:0").eval()
@@ -53,7 +55,7 @@ def test_fp32_forward_matches_reference_fixture(name):
             _close(h, extra["probe_hidden"][li])
 
 
-@pytest.mark.parametrize("name", ["rob2_first", "rob2_mean", "bert2_first", "rob12_first_L512"])
+@pytest.mark.parametrize("name", ["rob2_first", "rob2_mean", "bert2_first", "rob12_first_L512", "rob2_att_self_pool"])
 def test_bf16_forward_close_to_fp32_reference(name):
     cfg, seed, batch, expected, _ = U.load_golden(name)
     model = _model(cfg, seed, dtype="bf16")
