@@ -66,7 +66,7 @@ int otter_index_create(int d, int dtype, int device, otter_index** out);
 /* dtype OTTER_BF16 (no counterpart in the reference; BASELINE's 100M-row configuration): rows are
  * rounded to bfloat16 on add(), queries on search(); scores are accumulated in float32 and are
  * NOT IndexFlatIP's float32 scores (reported separately: recall@k against the OTTER_F32 index).
- * k <= 1024 for this storage type. */
+ * k <= 1280 for this storage type. */
 
 /* index.add(xb) — scripts/eval_ottqa_retrieval.py:109.
  * x: float32 row-major [n, d], host (x_is_device = 0) or device pointer.

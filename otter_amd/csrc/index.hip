@@ -1181,7 +1181,7 @@ void launch_scan16(const Scan16Args& a, int grid, hipStream_t st) {
 }
 
 // largest k the bf16-MFMA scan keeps per query (its compaction holds CAP / 64 composites per lane)
-constexpr int S16_MAX_K = 1024;
+constexpr int S16_MAX_K = 1280;   // (1280: top-1000 of an fp32 index plus its coarse-pass margin of k/8)
 
 template <int MODE>
 int pick_cfg16(int k, Scan16Cfg* out) {

@@ -37,7 +37,7 @@ def _search(xb, q, k, dtype="fp32"):
 
 
 @pytest.mark.parametrize("n,d,nq,k", [(70000, 768, 200, 100), (66000, 128, 700, 10), (131072, 768, 256, 1),
-                                        (80000, 64, 300, 500), (70001, 2304, 193, 100)])
+                                        (80000, 64, 300, 500), (70001, 2304, 193, 100), (90000, 128, 70, 1000)])
 def test_split_path_is_bit_exact(n, d, nq, k):
     xb, q = _mk(n, d, nq, seed=n + d + nq + k)
     D, I, fb = _search(xb, q, k)
@@ -110,7 +110,7 @@ def test_bf16_index_incremental_device_add_and_limits():
     flat_ip.check_topk(_bf16_round(xb), _bf16_round(q), D.cpu().numpy(), I.cpu().numpy(), 50, rtol=1e-5,
                        id_base=1 << 35)
     with pytest.raises(ValueError):
-        ix.search(q, 2000)                                  # the bf16 scan keeps at most 1024 per query
+        ix.search(q, 2000)                                  # the bf16 scan keeps at most 1280 per query
     ix.reset()
     D, I = ix.search(q, 5)
     assert (I == -1).all()
