@@ -324,7 +324,7 @@ def main():
     torch.cuda.empty_cache()
     enc = None
     if not args.no_encode:
-        enc = encode_leg(rank, world, local_rank, dist, max(2, args.steps // 4), 1, args.encode_batch,
+        enc = encode_leg(rank, world, local_rank, dist, max(4, args.steps // 2), min(3, max(1, args.warmup)), args.encode_batch,
                          world == 1 and not args.no_cpu_baseline)
 
     if rank == 0:
