@@ -95,6 +95,10 @@ int otter_index_search(otter_index* ix, const void* q, int64_t nq, int k,
 int otter_index_search_subset(otter_index* index, const void* q, int64_t nq, int k, const int64_t* ids, int m,
                               float* D, int64_t* I, int io_is_device, void* stream);
 
+/* rows [i0, i0 + n) of the index as float32 [n, d] (faiss: index.reconstruct_n(i0, n, out); what
+ * faiss.write_index serialises, scripts/eval_ottqa_retrieval.py:115).  A bf16 index returns its rounded values. */
+int otter_index_reconstruct_n(otter_index* index, int64_t i0, int64_t n, float* out, int out_is_device, void* stream);
+
 int64_t otter_index_ntotal(const otter_index* ix);
 int     otter_index_d(const otter_index* ix);
 

@@ -57,6 +57,7 @@ SIGNATURES = {
     "otter_encoder_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "otter_encoder_forward_hidden": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "otter_gemm_bf16": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
+    "otter_index_reconstruct_n": (c_int, [c_vp, c_i64, c_i64, c_vp, c_int, c_vp]),
     "otter_index_search_subset": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp]),
     "otter_ln_fold": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     "otter_gemm_bf16_ln": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,

@@ -1872,6 +1872,49 @@ int otter_index_search_subset(otter_index* ix, const void* q, int64_t nq, int k,
     return OTTER_OK;
 }
 
+// rows [i0, i0 + n) as float32 [n, d] (faiss: index.reconstruct_n(i0, n)); the bf16 index returns its rounded values
+__global__ void unpack_rows_kernel(const float* __restrict__ x32, const unsigned short* __restrict__ x16, float* dst,
+                                   long long i0, long long n, int d, int ld) {
+    const long long total = n * d;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / d;
+        const int c = (int)(i - r * d);
+        dst[i] = x32 ? x32[(i0 + r) * ld + c] : __uint_as_float((u32)x16[plane_index(i0 + r, c, ld)] << 16);
+    }
+}
+
+int otter_index_reconstruct_n(otter_index* ix, int64_t i0, int64_t n, float* out, int out_is_device, void* stream) {
+    if (!ix) return set_err(OTTER_EINVAL, "reconstruct_n: index is NULL");
+    if (i0 < 0 || n < 0 || i0 + n > ix->n) return set_err(OTTER_EINVAL, "reconstruct_n: rows [%lld, %lld) outside [0, %lld)",
+                                                          (long long)i0, (long long)(i0 + n), (long long)ix->n);
+    if (n == 0) return OTTER_OK;
+    if (!out) return set_err(OTTER_EINVAL, "reconstruct_n: out is NULL");
+    DeviceGuard g(ix->device);
+    if (!g.ok) return set_err(OTTER_EHIP, "reconstruct_n: hipSetDevice(%d) failed", ix->device);
+    hipStream_t st = (hipStream_t)stream;
+    const long long slab = 1 << 16;
+    for (long long lo = 0; lo < n; lo += slab) {
+        const long long c = std::min<long long>(slab, n - lo);
+        float* dst = out + (size_t)lo * ix->d;
+        if (!out_is_device) {
+            int rc = ix->io_q.reserve((size_t)c * ix->d * sizeof(float));
+            if (rc) return rc;
+            dst = (float*)ix->io_q.p;
+        }
+        const long long total = c * ix->d;
+        hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 8192)), dim3(256), 0, st,
+                           ix->dtype == OTTER_F32 ? (const float*)ix->x : (const float*)nullptr,
+                           (const unsigned short*)ix->x16, dst, (long long)(i0 + lo), c, ix->d, ix->ld);
+        OTTER_HIP_TRY(hipGetLastError());
+        if (!out_is_device) {
+            OTTER_HIP_TRY(hipMemcpyAsync(out + (size_t)lo * ix->d, dst, (size_t)c * ix->d * sizeof(float), hipMemcpyDeviceToHost,
+                                         st));
+            OTTER_HIP_TRY(hipStreamSynchronize(st));   // the staging slab is reused
+        }
+    }
+    return OTTER_OK;
+}
+
 int64_t otter_index_ntotal(const otter_index* ix) { return ix ? ix->n : -1; }
 int otter_index_d(const otter_index* ix) { return ix ? ix->d : -1; }
 

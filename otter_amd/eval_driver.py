@@ -21,6 +21,7 @@ MFMA-bound); everything after the search is the reference's own CPU string work,
 import argparse
 import collections
 import json
+import os
 import logging
 import unicodedata
 
@@ -159,6 +160,8 @@ def main(argv=None):
     ap.add_argument("--id2doc_path", type=str, required=True)
     ap.add_argument("--output_save_path", type=str, default="")
     ap.add_argument("--beam_size", type=int, default=100)
+    ap.add_argument("--faiss_save_path", type=str, default="",
+                    help="flat IndexFlatIP file: read instead of building when it exists (scripts/eval_ottqa_retrieval.py:106-107)")
     ap.add_argument("--eval_only_ans", action="store_true")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO)
@@ -167,7 +170,11 @@ def main(argv=None):
     q = np.load(args.query_embeddings_path).astype("float32")
     xb = np.load(args.corpus_embeddings_path, mmap_mode="r")
     logger.info("corpus size: %s", (xb.shape,))
-    index = build_index(xb)
+    if args.faiss_save_path and os.path.exists(args.faiss_save_path):
+        from .index_io import read_index
+        index = read_index(args.faiss_save_path)
+    else:
+        index = build_index(xb)
     id2doc = load_id2doc(args.id2doc_path)
     D, I = index.search(q, args.beam_size)          # one batched call (the reference: nq = 1 per call, 24 processes)
     index.close()

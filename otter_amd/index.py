@@ -189,6 +189,14 @@ class IndexFlatIP:
             return D, pos
         return D, I
 
+    def reconstruct_n(self, i0=0, n=None):
+        """float32 [n, d] copy of rows [i0, i0 + n) (faiss: index.reconstruct_n)."""
+        n = self.ntotal - i0 if n is None else int(n)
+        out = np.empty((n, self.d), dtype=np.float32)
+        _lib.check(self._lib.otter_index_reconstruct_n(self._h, int(i0), n, ctypes.c_void_p(out.ctypes.data), 0,
+                                                       _stream_ptr(self.device)), "otter_index_reconstruct_n")
+        return out
+
     @property
     def last_fallback(self):
         """Queries of the last search() that the coarse bf16 pass could not prove and the exact kernel re-did."""

@@ -156,3 +156,37 @@ def test_whitening_matches_the_reference_golden():
     allv = np.concatenate([w1, w2], 0).astype(np.float64)
     np.testing.assert_allclose(np.cov(allv.T), np.eye(allv.shape[1]), atol=5e-3)
     assert W.transform_and_normalize(g["e1"]) is g["e1"] or np.array_equal(W.transform_and_normalize(g["e1"]), g["e1"])
+
+
+def test_index_file_round_trip_and_validation(tmp_path):
+    """otter_amd.index_io on the host: faiss' IndexFlatIP file layout as restated there (parity unpinned against
+    real faiss files: none ship with the reference and faiss is absent), both vector-count conventions, and
+    loud refusal of truncated / foreign files."""
+    import struct
+    from otter_amd import index_io as IO
+
+    class Fake:
+        def __init__(self, x):
+            self.x, self.d, self.ntotal = x, x.shape[1], x.shape[0]
+
+        def reconstruct_n(self, i0, n):
+            return self.x[i0:i0 + n]
+
+    x = np.random.RandomState(4).randn(1000, 24).astype(np.float32)
+    p = str(tmp_path / "flat.index")
+    IO.write_index(Fake(x), p)
+    d, xb = IO.read_flat(p)
+    assert d == 24 and xb.shape == (1000, 24) and np.array_equal(np.asarray(xb), x)
+    raw = bytearray(open(p, "rb").read())
+    assert raw[:4] == b"IxFI" and len(raw) == 37 + 8 + x.nbytes
+    # faiss <= 1.7.0 stores the count in units of 4 floats
+    old = bytearray(raw)
+    old[37:45] = struct.pack("<Q", x.size // 4)
+    open(p, "wb").write(old)
+    assert np.array_equal(np.asarray(IO.read_flat(p)[1]), x)
+    for bad in (raw[:-4], b"IHNf" + bytes(raw[4:]), bytes(raw[:37]) + struct.pack("<Q", 7) + bytes(raw[45:])):
+        open(p, "wb").write(bad)
+        with pytest.raises(ValueError):
+            IO.read_flat(p)
+    IO.write_index(Fake(x[:0]), p)
+    assert IO.read_flat(p)[1].shape == (0, 24)

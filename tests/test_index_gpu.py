@@ -250,3 +250,34 @@ def test_subset_search_device_io_id_base_and_errors():
     with pytest.raises(NotImplementedError):
         ib.search_subsets(q, 8, np.zeros((6, 4), np.int64))
     ib.close()
+
+
+def test_reconstruct_and_index_file_round_trip(tmp_path):
+    from otter_amd import index_io as IO
+    from otter_amd.index import IndexFlatIP
+    xb, q = _mk(70000, 100, 9, seed=8)
+    ix = IndexFlatIP(100)
+    ix.add(xb[:30000])
+    ix.add(xb[30000:])
+    np.testing.assert_array_equal(ix.reconstruct_n(), xb)
+    np.testing.assert_array_equal(ix.reconstruct_n(65530, 100), xb[65530:65630])
+    with pytest.raises(ValueError):
+        ix.reconstruct_n(69999, 2)
+    D, I = ix.search(q, 10)
+    path = str(tmp_path / "corpus.index")
+    IO.write_index(ix, path)
+    ix.close()
+    ix2 = IO.read_index(path)
+    assert ix2.ntotal == 70000 and ix2.d == 100
+    D2, I2 = ix2.search(q, 10)
+    ix2.close()
+    np.testing.assert_array_equal(I, I2)
+    np.testing.assert_array_equal(D.view(np.uint32), D2.view(np.uint32))
+    # the bf16 index hands back its rounded rows (tile-blocked storage underneath)
+    import torch
+    ib = IndexFlatIP(100, dtype="bf16")
+    ib.add(xb[:1000])
+    ib.add(xb[1000:3001])
+    exp = torch.from_numpy(xb[:3001]).to(torch.bfloat16).float().numpy()
+    np.testing.assert_array_equal(ib.reconstruct_n(), exp)
+    ib.close()
