@@ -450,6 +450,8 @@ struct Scan16Args {
     int ldk;            // row length in bf16 elements: ld (MODE 0) or 2 * ld (MODE 1), multiple of 64
     int nq, nq_pad, k;
     int qtiles, strips, total_tiles;
+    int tile_begin;     // first tile of this launch (tiles below belong to the sample pass)
+    const u32* thr0;    // [nq_pad] initial score-key threshold per query (null: none)
     u32* sync;          // [strips] zeroed per launch, or null: soft tile barrier among the workgroups of a strip
 };
 
@@ -479,14 +481,14 @@ __global__ __launch_bounds__(512, 2) void scan16_kernel(Scan16Args a) {
     const int strip = wg / a.qtiles;           // an XCD's workgroups share corpus strips
     const int qt = wg - strip * a.qtiles;
     const int q0 = qt * S16_BQ;
-    const int t0 = (int)(((long long)strip * a.total_tiles) / a.strips);
-    const int t1 = (int)(((long long)(strip + 1) * a.total_tiles) / a.strips);
+    const int t0 = a.tile_begin + (int)(((long long)strip * a.total_tiles) / a.strips);
+    const int t1 = a.tile_begin + (int)(((long long)(strip + 1) * a.total_tiles) / a.strips);
     const int KT = a.ldk >> 6;
     const int total_stages = (t1 - t0) * KT;
 
     for (int i = tid; i < S16_BQ; i += 512) {
         sCnt[i] = 0;
-        sThr[i] = (q0 + i < a.nq) ? 0u : 0xFFFFFFFFu;
+        sThr[i] = (q0 + i < a.nq) ? (a.thr0 ? a.thr0[q0 + i] : 0u) : 0xFFFFFFFFu;
     }
     if (tid == 0) *sFlag = 0;
     u64* candBase = a.cand + ((size_t)strip * a.nq_pad + q0) * CAP;
@@ -1452,7 +1454,58 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
                      nullptr, nullptr, st);
 }
 
-int launch_scan16_timed(otter_index* ix, const Scan16Cfg& cfg, const Scan16Args& sa, int grid, hipStream_t st) {
+// common part of the two bf16-MFMA searches: scan `Xk` (bf16 planes of ldk elements per row) for the
+// queries in ix->qs and merge to (Dc, Ic) [nq, kk].
+// Sample pass (as in search_chunk): on a large corpus every strip would otherwise spend its first tiles
+// learning a threshold, appending whole tiles of candidates and compacting after each.  The first
+// sample_tiles tiles are scanned by all workgroups first and merged; the key of each query's kk-th
+// best among them seeds every strip of the main scan.  Exact: the sample rows have the smallest ids,
+// so a later row that only ties that key ranks behind kk sample rows.
+template <int MODE>
+int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int kk, float* Dc, long long* Ic,
+                     hipStream_t st) {
+    Scan16Cfg cfg;
+    int rc = pick_cfg16<MODE>(kk, &cfg);
+    if (rc) return rc;
+    const long long nq_pad = round_up64(nq, S16_BQ);
+    const int qtiles = (int)(nq_pad / S16_BQ);
+    const int total_tiles = (int)((ix->n + S16_BM - 1) / S16_BM);
+    const int wgs = std::max(1, ix->ncu / qtiles);
+    static const char* no_sample = getenv("OTTER_NO_SAMPLE");
+    // 4 / 2 / 1 tiles per workgroup (many strips = few tiles each: a short sample already pays), and at least
+    // 64 kk rows so that the seeded threshold is selective
+    const int per_wg = wgs <= 32 ? 4 : wgs <= 128 ? 2 : 1;
+    int sample_tiles = std::max(per_wg * wgs, (int)((64ll * kk + S16_BM - 1) / S16_BM));
+    const bool sample = !no_sample && total_tiles >= 8 * sample_tiles;
+    if (!sample) sample_tiles = 0;
+    const int main_tiles = total_tiles - sample_tiles;
+    const int strips = std::min(wgs, main_tiles);
+    const int strips_s = sample ? std::min(wgs, sample_tiles) : 0;
+    if ((rc = ix->cand.reserve((size_t)std::max(strips, strips_s) * nq_pad * cfg.cap * sizeof(u64)))) return rc;
+    if ((rc = ix->cnt.reserve((size_t)std::max(strips, strips_s) * nq_pad * sizeof(u32)))) return rc;
+    if (sample) {
+        if ((rc = ix->smp.reserve((size_t)nq_pad * kk * sizeof(u64)))) return rc;
+        if ((rc = ix->smpcnt.reserve((size_t)nq_pad * sizeof(u32)))) return rc;
+        if ((rc = ix->thr0.reserve((size_t)nq_pad * sizeof(u32)))) return rc;
+    }
+    Scan16Args sa;
+    sa.X = (const char*)Xk;
+    sa.Q = (const char*)ix->qs.p;
+    sa.cand = (u64*)ix->cand.p;
+    sa.cnt = (u32*)ix->cnt.p;
+    sa.n = ix->n;
+    sa.ldk = ldk;
+    sa.nq = (int)nq;
+    sa.nq_pad = (int)nq_pad;
+    sa.k = kk;
+    sa.qtiles = qtiles;
+    sa.sync = nullptr;
+    static const char* nosync = getenv("OTTER_NO_TILE_SYNC");
+    const bool tsync = qtiles > 1 && !(nosync && nosync[0] == '1');
+    if (tsync) {
+        if ((rc = ix->tsync.reserve((size_t)wgs * sizeof(u32)))) return rc;
+        sa.sync = (u32*)ix->tsync.p;
+    }
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     const bool timed = ix->timing && ix->ev_pending.size() < 4096;
     if (timed) {
@@ -1465,52 +1518,33 @@ int launch_scan16_timed(otter_index* ix, const Scan16Cfg& cfg, const Scan16Args&
         }
         OTTER_HIP_TRY(hipEventRecord(ev.first, st));
     }
-    cfg.launch(sa, grid, st);
+    if (sample) {
+        sa.strips = strips_s;
+        sa.total_tiles = sample_tiles;
+        sa.tile_begin = 0;
+        sa.thr0 = nullptr;
+        if (tsync) OTTER_HIP_TRY(hipMemsetAsync(ix->tsync.p, 0, (size_t)wgs * sizeof(u32), st));
+        cfg.launch(sa, qtiles * strips_s, st);
+        OTTER_HIP_TRY(hipGetLastError());
+        if ((rc = run_merge(ix, (const u64*)ix->cand.p, (const u32*)ix->cnt.p, cfg.cap, strips_s, nq, nq_pad, kk, false,
+                            nullptr, nullptr, nullptr, nullptr, (u64*)ix->smp.p, (u32*)ix->smpcnt.p, (u32*)ix->thr0.p,
+                            st)))
+            return rc;
+    }
+    sa.strips = strips;
+    sa.total_tiles = main_tiles;
+    sa.tile_begin = sample_tiles;
+    sa.thr0 = sample ? (const u32*)ix->thr0.p : nullptr;
+    if (tsync) OTTER_HIP_TRY(hipMemsetAsync(ix->tsync.p, 0, (size_t)wgs * sizeof(u32), st));
+    cfg.launch(sa, qtiles * strips, st);
     OTTER_HIP_TRY(hipGetLastError());
     if (timed) {
         OTTER_HIP_TRY(hipEventRecord(ev.second, st));
         ix->ev_pending.push_back(ev);
     }
-    return OTTER_OK;
-}
-
-// common part of the two bf16-MFMA searches: scan `Xk` (bf16 rows of ldk elements) for the queries
-// in ix->qs and merge to (Dc, Ic) [nq, kk]
-template <int MODE>
-int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int kk, float* Dc, long long* Ic,
-                     hipStream_t st) {
-    Scan16Cfg cfg;
-    int rc = pick_cfg16<MODE>(kk, &cfg);
-    if (rc) return rc;
-    const long long nq_pad = round_up64(nq, S16_BQ);
-    const int qtiles = (int)(nq_pad / S16_BQ);
-    const int total_tiles = (int)((ix->n + S16_BM - 1) / S16_BM);
-    int strips = std::min(std::max(1, ix->ncu / qtiles), total_tiles);
-    if ((rc = ix->cand.reserve((size_t)strips * nq_pad * cfg.cap * sizeof(u64)))) return rc;
-    if ((rc = ix->cnt.reserve((size_t)strips * nq_pad * sizeof(u32)))) return rc;
-    Scan16Args sa;
-    sa.X = (const char*)Xk;
-    sa.Q = (const char*)ix->qs.p;
-    sa.cand = (u64*)ix->cand.p;
-    sa.cnt = (u32*)ix->cnt.p;
-    sa.n = ix->n;
-    sa.ldk = ldk;
-    sa.nq = (int)nq;
-    sa.nq_pad = (int)nq_pad;
-    sa.k = kk;
-    sa.qtiles = qtiles;
-    sa.strips = strips;
-    sa.total_tiles = total_tiles;
-    sa.sync = nullptr;
-    static const char* nosync = getenv("OTTER_NO_TILE_SYNC");
-    if (qtiles > 1 && !(nosync && nosync[0] == '1')) {
-        if ((rc = ix->tsync.reserve((size_t)strips * sizeof(u32)))) return rc;
-        OTTER_HIP_TRY(hipMemsetAsync(ix->tsync.p, 0, (size_t)strips * sizeof(u32), st));
-        sa.sync = (u32*)ix->tsync.p;
-    }
-    if ((rc = launch_scan16_timed(ix, cfg, sa, qtiles * strips, st))) return rc;
     return run_merge(ix, (const u64*)ix->cand.p, (const u32*)ix->cnt.p, cfg.cap, strips, nq, nq_pad, kk, true, Dc, Ic,
-                     nullptr, nullptr, nullptr, nullptr, nullptr, st);
+                     sample ? (const u64*)ix->smp.p : nullptr, sample ? (const u32*)ix->smpcnt.p : nullptr, nullptr,
+                     nullptr, nullptr, st);
 }
 
 // OTTER_BF16 index: queries rounded to bf16, scores accumulated in fp32
