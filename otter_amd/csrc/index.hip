@@ -452,7 +452,6 @@ struct Scan16Args {
     int qtiles, strips, total_tiles;
     int tile_begin;     // first tile of this launch (tiles below belong to the sample pass)
     const u32* thr0;    // [nq_pad] initial score-key threshold per query (null: none)
-    u32* sync;          // [strips] zeroed per launch, or null: soft tile barrier among the workgroups of a strip
 };
 
 constexpr int S16_HT = 16384, S16_BUF = 4 * S16_HT;
@@ -691,21 +690,6 @@ __global__ __launch_bounds__(512, 2) void scan16_kernel(Scan16Args a) {
                 wg_barrier();
                 if (g == 0) {
                     epilogue(c_tile);
-                    // Soft tile barrier: the qtiles workgroups of a strip stream the same corpus tiles and
-                    // only hit in L2 while they stay within a few K-steps of each other.  Arrive, then wait
-                    // -- at most ~2 us, never unbounded: co-residency of the partners is likely, not
-                    // guaranteed -- until every partner has finished this tile.
-                    if (a.sync && wave == 0) {
-                        u32* ctr = a.sync + strip;
-                        if (lane == 0) (void)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const u32 target = (u32)a.qtiles * (u32)(c_tile - t0 + 1);
-                        for (int it = 0; it < 6; ++it) {
-                            const u32 v = __builtin_amdgcn_readfirstlane(
-                                __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                            if (v >= target) break;
-                            __builtin_amdgcn_s_sleep(4);
-                        }
-                    }
                     wg_barrier();        // group 0 waits for group 1: every wave is past its epilogue
                 }
                 if (__builtin_amdgcn_readfirstlane(*sFlag)) compact_pass(false);   // same barriers for all waves
@@ -1213,7 +1197,7 @@ struct otter_index {
     long long xs_rows = 0, xs_cap = 0;
     bool xs_failed = false, no_split = false;
     long long last_fallback = 0;    // queries of the last split search that went to the exact kernel
-    otter::DevBuf qs, qnorm2, cD, cI, rs, rscnt, flags, fb_q, fb_D, fb_I, tsync;
+    otter::DevBuf qs, qnorm2, cD, cI, rs, rscnt, flags, fb_q, fb_D, fb_I;
     otter::DevBuf qpad, cand, cnt, lvl[2], lvlcnt[2], smp, smpcnt, thr0, io_q, io_D, io_I;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
@@ -1499,13 +1483,6 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
     sa.nq_pad = (int)nq_pad;
     sa.k = kk;
     sa.qtiles = qtiles;
-    sa.sync = nullptr;
-    static const char* nosync = getenv("OTTER_NO_TILE_SYNC");
-    const bool tsync = qtiles > 1 && !(nosync && nosync[0] == '1');
-    if (tsync) {
-        if ((rc = ix->tsync.reserve((size_t)wgs * sizeof(u32)))) return rc;
-        sa.sync = (u32*)ix->tsync.p;
-    }
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     const bool timed = ix->timing && ix->ev_pending.size() < 4096;
     if (timed) {
@@ -1523,7 +1500,6 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
         sa.total_tiles = sample_tiles;
         sa.tile_begin = 0;
         sa.thr0 = nullptr;
-        if (tsync) OTTER_HIP_TRY(hipMemsetAsync(ix->tsync.p, 0, (size_t)wgs * sizeof(u32), st));
         cfg.launch(sa, qtiles * strips_s, st);
         OTTER_HIP_TRY(hipGetLastError());
         if ((rc = run_merge(ix, (const u64*)ix->cand.p, (const u32*)ix->cnt.p, cfg.cap, strips_s, nq, nq_pad, kk, false,
@@ -1535,7 +1511,6 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
     sa.total_tiles = main_tiles;
     sa.tile_begin = sample_tiles;
     sa.thr0 = sample ? (const u32*)ix->thr0.p : nullptr;
-    if (tsync) OTTER_HIP_TRY(hipMemsetAsync(ix->tsync.p, 0, (size_t)wgs * sizeof(u32), st));
     cfg.launch(sa, qtiles * strips, st);
     OTTER_HIP_TRY(hipGetLastError());
     if (timed) {
@@ -2003,7 +1978,7 @@ void otter_index_destroy(otter_index* ix) {
     if (ix->x) (void)hipFree(ix->x);
     if (ix->x16) (void)hipFree(ix->x16);
     for (otter::DevBuf* b : {&ix->xs, &ix->xnorm2, &ix->xnmax, &ix->qs, &ix->qnorm2, &ix->cD, &ix->cI, &ix->rs,
-                             &ix->rscnt, &ix->flags, &ix->fb_q, &ix->fb_D, &ix->fb_I, &ix->tsync})
+                             &ix->rscnt, &ix->flags, &ix->fb_q, &ix->fb_D, &ix->fb_I})
         b->release();
     ix->qpad.release();
     ix->cand.release();
