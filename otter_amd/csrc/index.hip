@@ -1456,11 +1456,14 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
     const int total_tiles = (int)((ix->n + S16_BM - 1) / S16_BM);
     const int wgs = std::max(1, ix->ncu / qtiles);
     static const char* no_sample = getenv("OTTER_NO_SAMPLE");
-    // 4 / 2 / 1 tiles per workgroup (many strips = few tiles each: a short sample already pays), and at least
-    // 64 kk rows so that the seeded threshold is selective
-    const int per_wg = wgs <= 32 ? 4 : wgs <= 128 ? 2 : 1;
-    int sample_tiles = std::max(per_wg * wgs, (int)((64ll * kk + S16_BM - 1) / S16_BM));
-    const bool sample = !no_sample && total_tiles >= 8 * sample_tiles;
+    // about 1/16 of the corpus (measured plateau: 1/16 .. 1/8; the sample pass itself runs at full occupancy and
+    // its own thresholds tighten as it goes), whole tiles per workgroup, at least 64 kk rows so that the seeded
+    // threshold is selective, at most 1/8 of the corpus
+    static const char* per_env = getenv("OTTER_SAMPLE_PER_WG");   // tuning runs only
+    int sample_tiles = std::max(total_tiles / 16, (int)((64ll * kk + S16_BM - 1) / S16_BM));
+    sample_tiles = (sample_tiles + wgs - 1) / wgs * wgs;
+    if (per_env) sample_tiles = std::max(1, atoi(per_env)) * wgs;
+    const bool sample = !no_sample && sample_tiles <= total_tiles / 8;
     if (!sample) sample_tiles = 0;
     const int main_tiles = total_tiles - sample_tiles;
     const int strips = std::min(wgs, main_tiles);
