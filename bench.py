@@ -295,6 +295,7 @@ def main():
     # (2) the first 65,536 rows re-scored with torch in float64 for 8 queries
     ok = True
     fallback = index.last_fallback
+    refined = index.last_refined
     if rank == 0 and world > 1:
         # merged result of the sharded search: sorted, unique global ids in range, and this rank's own shard
         # result must be a subsequence-by-score of it (every local hit that beats the merged k-th is present)
@@ -333,10 +334,13 @@ def main():
         kern_ms = scan_ms / max(launches, 1)
         flops = 2.0 * n * d * nq
         split = nq >= 65 and n >= 65536 and not os.environ.get("OTTER_NO_SPLIT")
-        if split:   # coarse pass on bf16 hi/lo planes: 3 MFMA products per term
-            kernel_flops, peak = 3.0 * flops, PEAK_BF16_MFMA_TFLOPS
-            kname = ("scan16_kernel<1,8> (256x256 tile, v_mfma_f32_16x16x32_bf16 on hi/lo bf16 planes of the fp32 "
-                     "operands: hi*hi + hi*lo + lo*hi, fused top-k filter; then exact fp32 re-scoring + margin proof). "
+        two = os.environ.get("OTTER_SPLIT_MODE") != "1"
+        if split:   # coarse pass on bf16 hi/lo planes: 2 (default) or 3 MFMA products per term
+            kernel_flops, peak = (2.0 if two else 3.0) * flops, PEAK_BF16_MFMA_TFLOPS
+            kname = ("scan16_kernel<%d,8> (256x256 tile, v_mfma_f32_16x16x32_bf16 on hi/lo bf16 planes of the fp32 "
+                     "operands: %s, fused top-k filter; then exact fp32 re-scoring + margin proof; unproven queries "
+                     "go to the three-product pass / the exact kernel). " % (2 if two else 1,
+                     "x_hi*q_hi + x_lo*q_hi" if two else "x_hi*q_hi + x_hi*q_lo + x_lo*q_hi") +
                      "kernel_ms is one HIP-event bracket per search on the launch stream = TWO dispatches of this kernel "
                      "(threshold-seeding sample pass over the first tiles, then the main scan) and the ~0.12 ms merge "
                      "between them: rocprof's TotalDurationNs of scan16_kernel / steps + that merge")
@@ -355,7 +359,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16x3 split of f32 operands, f32 accumulate, exact f32 re-scoring (results = f32 IndexFlatIP)"
+            "dtype": "bf16 hi/lo split of f32 operands on the matrix cores, f32 accumulate, exact f32 re-scoring (results = f32 IndexFlatIP)"
                      if split else "f32",
             "data": "synthetic",
             "config": {"workload": "configs[1]: exact top-%d IP search, %d-query batch over %dx%d fp32 corpus "
@@ -373,6 +377,7 @@ def main():
                          "f32_equivalent_vs_f32_matrix_peak": (flops / (kern_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS)
                          if kern_ms > 0 else 0.0,
                          "exact_fallback_queries_last_step": int(fallback),
+                         "refined_queries_last_step": int(refined),
                          "algorithmic_flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": float(n) * d * 4 + nq * d * 4 + nq * k * 12,
                          "hbm_frac_if_bandwidth_bound": (float(n) * d * 4 / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS)

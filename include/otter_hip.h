@@ -128,6 +128,9 @@ int otter_index_timing(otter_index* ix, double* scan_ms, int64_t* scan_launches)
  * k; a query without a proof is searched again by the exact float32 kernel.  Returns how many
  * queries of the last search() took that second route (0 in the usual case). */
 int64_t otter_index_last_fallback(const otter_index* ix);
+/* Queries of the last search() that the two-product coarse pass could not prove and that were searched again
+ * with the three-product pass (or, if fewer than 65, by the exact kernel); 0 on the other paths. */
+int64_t otter_index_last_refined(const otter_index* index);
 
 /* Final merge of the row-sharded search: G sorted candidate lists per query
  * (Dc float32 [G, nq, k], Ic int64 [G, nq, k], device pointers, as returned

@@ -47,6 +47,7 @@ SIGNATURES = {
     "otter_index_reset": (c_int, [c_vp]),
     "otter_index_set_id_base": (c_int, [c_vp, c_i64]),
     "otter_index_last_fallback": (c_i64, [c_vp]),
+    "otter_index_last_refined": (c_i64, [c_vp]),
     "otter_index_destroy": (None, [c_vp]),
     "otter_index_set_timing": (c_int, [c_vp, c_int]),
     "otter_index_timing": (c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),

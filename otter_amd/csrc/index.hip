@@ -587,15 +587,18 @@ __global__ __launch_bounds__(512, 2) void scan16_kernel(Scan16Args a) {
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb) mfma(acc[4 * mq + mb][2 * nq + nb], Wf[nq][nb][ks], X[mb][ks]);
         } else {
-            // chunk 0 / 1 = hi / lo planes of the same 32 values of k: hi hi + hi lo + lo hi
+            // chunk 0 / 1 = hi / lo planes of the same 32 values of k; W = corpus rows, X = queries:
+            // x_hi q_hi + x_hi q_lo + x_lo q_hi (MODE 1); MODE 2 leaves out x_hi q_lo (error |q - q_hi| |x|)
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) mfma(acc[4 * mq + mb][2 * nq + nb], Wf[nq][nb][0], X[mb][0]);
+            if (MODE == 1) {
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
+                for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) mfma(acc[4 * mq + mb][2 * nq + nb], Wf[nq][nb][0], X[mb][1]);
+                    for (int nb = 0; nb < 2; ++nb) mfma(acc[4 * mq + mb][2 * nq + nb], Wf[nq][nb][0], X[mb][1]);
+            }
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -735,16 +738,17 @@ __global__ void to_bf16_rows_kernel(const float* __restrict__ src, unsigned shor
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, long long sld,
                                                          unsigned short* __restrict__ dst, long long rows,
                                                          long long rows_pad, int d, int ld, float* norm2,
-                                                         long long row0) {
+                                                         long long row0, float* res2 = nullptr) {
     const int lane = threadIdx.x & 63;
     const long long w0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
     const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
     for (long long r = w0; r < rows_pad; r += nw) {      // one wave per row
-        float ss = 0.f;
+        float ss = 0.f, rr = 0.f;
         for (int c = lane; c < ld; c += 64) {
             const float v = (r < rows && c < d) ? src[r * sld + c] : 0.0f;
             const __bf16 hi = (__bf16)v;
             const __bf16 lo = (__bf16)(v - (float)hi);
+            rr += (v - (float)hi) * (v - (float)hi);
             unsigned short* o = dst + plane_index(row0 + r, (c >> 5) * 64 + (c & 31), 2 * ld);   // lo: +32, same slab
             o[0] = __builtin_bit_cast(unsigned short, hi);
             o[32] = __builtin_bit_cast(unsigned short, lo);
@@ -754,6 +758,11 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
             if (lane == 0) norm2[r] = ss;
+        }
+        if (res2) {      // |v - hi|^2: what a product without the lo plane of this row leaves out
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) rr += __shfl_xor(rr, o);
+            if (lane == 0) res2[r] = rr;
         }
     }
 }
@@ -850,9 +859,10 @@ __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
 // A query's exact top k is proven complete when its k-th exact score exceeds every score a row
 // OUTSIDE the kc coarse candidates can have: (smallest kept coarse score) + eps,
 // eps = rel * |q| * max |x|.  Otherwise (or on any non-finite value) the query is flagged.
+// qres2 (two-product coarse pass): |q - q_hi|^2; that pass leaves out x . (q - q_hi), at most |q - q_hi| |x|.
 __global__ void margin_check_kernel(const float* Dexact, const float* Dcoarse, const long long* Icoarse,
                                     const float* qnorm2, const u32* xnorm2_max, float rel, long long nq, int k, int kc,
-                                    long long n, u32* flags, u32* nflag) {
+                                    long long n, u32* flags, u32* nflag, const float* qres2) {
     const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (q >= nq) return;
     bool ok;
@@ -861,7 +871,9 @@ __global__ void margin_check_kernel(const float* Dexact, const float* Dcoarse, c
     } else {
         const float tc = Dcoarse[q * kc + kc - 1];             // n > kc: the coarse list is full
         const float ek = Dexact[q * k + k - 1];
-        const float eps = rel * sqrtf(qnorm2[q]) * sqrtf(__uint_as_float(*xnorm2_max));
+        const float xmax = sqrtf(__uint_as_float(*xnorm2_max));
+        float eps = rel * sqrtf(qnorm2[q]) * xmax;
+        if (qres2) eps += 1.001f * sqrtf(qres2[q]) * xmax;
         ok = Icoarse[q * kc + kc - 1] >= 0 && ek > tc + eps;    // false on NaN / inf bounds
     }
     flags[q] = ok ? 0u : 1u;
@@ -1171,7 +1183,7 @@ constexpr int S16_MAX_K = 1280;   // (1280: top-1000 of an fp32 index plus its c
 
 template <int MODE>
 int pick_cfg16(int k, Scan16Cfg* out) {
-    if (k <= 128) *out = Scan16Cfg{8 * 64, &launch_scan16<MODE, 8>};
+    if (k <= 160) *out = Scan16Cfg{8 * 64, &launch_scan16<MODE, 8>};   // 512 slots: kk + a 256-row tile fit
     else if (k <= 512) *out = Scan16Cfg{20 * 64, &launch_scan16<MODE, 20>};
     else if (k <= S16_MAX_K) *out = Scan16Cfg{36 * 64, &launch_scan16<MODE, 36>};
     else return set_err(OTTER_EINVAL, "search: k=%d exceeds %d, the bound of the bf16 scan", k, S16_MAX_K);
@@ -1197,6 +1209,9 @@ struct otter_index {
     long long xs_rows = 0, xs_cap = 0;
     bool xs_failed = false, no_split = false;
     long long last_fallback = 0;    // queries of the last split search that went to the exact kernel
+    long long last_refined = 0;     // ... that the two-product pass could not prove (three-product pass or exact kernel)
+    bool two_prod_off = false;      // the two-product pass failed for > 1/4 of a batch: this corpus starts with three
+    otter::DevBuf qres2, fb2_q, fb2_D, fb2_I;
     otter::DevBuf qs, qnorm2, cD, cI, rs, rscnt, flags, fb_q, fb_D, fb_I;
     otter::DevBuf qpad, cand, cnt, lvl[2], lvlcnt[2], smp, smpcnt, thr0, io_q, io_D, io_I;
     bool timing = false;
@@ -1303,8 +1318,9 @@ int run_merge(otter_index* ix, const u64* in, const u32* in_cnt, int cap_in, int
 }
 
 int search_chunk_bf16(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st);
-int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, int kc, float* D, long long* I,
-                       hipStream_t st);
+int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st,
+                       int mode);
+int split_kc(int k, int mode, int d);
 int ensure_split_planes(otter_index* ix, hipStream_t st);
 
 // one scan + merge over queries [qd, qd + nq) (device pointers), results to device D/I
@@ -1313,13 +1329,18 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
     {
         // MFMA-bound batches on a large corpus: coarse pass on the bf16 matrix cores + exact re-scoring
         static const char* no_split_env = getenv("OTTER_NO_SPLIT");
-        const int kc = k + std::max(28, k / 8);
         static const char* split_min_env = getenv("OTTER_SPLIT_MIN_NQ");   // tuning runs only
         static const int split_min = split_min_env ? atoi(split_min_env) : 65;   // above the 64-query tile of the exact kernel
-        if (!no_split_env && !ix->no_split && nq >= split_min && ix->n >= 65536 && kc <= S16_MAX_K) {
+        static const char* mode_env = getenv("OTTER_SPLIT_MODE");          // "1": three-product coarse pass first
+        if (!no_split_env && !ix->no_split && nq >= split_min && ix->n >= 65536 && split_kc(k, 1, ix->d) <= S16_MAX_K) {
             const int rs = ensure_split_planes(ix, st);
             if (rs < 0) return rs;
-            if (rs == 0) return search_chunk_split(ix, qd, nq, k, kc, D, I, st);
+            if (rs == 0) {
+                const bool two = !(mode_env && mode_env[0] == '1') && !ix->two_prod_off && split_kc(k, 2, ix->d) <= S16_MAX_K;
+                ix->last_fallback = 0;
+                ix->last_refined = 0;
+                return search_chunk_split(ix, qd, nq, k, D, I, st, two ? 2 : 1);
+            }
         }
     }
     ScanCfg cfg;
@@ -1582,17 +1603,31 @@ int ensure_split_planes(otter_index* ix, hipStream_t st) {
 
 int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st);
 
-// Exact fp32 search of a large query batch through the bf16 matrix cores: coarse top-(k + margin)
-// on hi/lo bf16 planes, exact re-scoring of those candidates with scan_kernel's fp32 chain, a
-// per-query proof that no other row can reach the top k, and scan_kernel itself for the (rare)
-// queries without a proof.  Results are identical to search_chunk's.
-int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, int kc, float* D, long long* I,
-                       hipStream_t st) {
+// Exact fp32 search of a large query batch through the bf16 matrix cores: coarse top-kc on hi/lo bf16
+// planes, exact re-scoring of those candidates with scan_kernel's fp32 chain, and a per-query proof that
+// no other row can reach the top k.  Results are identical to search_chunk's.
+//   mode 2: coarse score x_hi q_hi + x_lo q_hi (two products).  Left out: x . (q - q_hi), at most
+//           |q - q_hi| max|x| (~1.6e-3 |q||x|, i.e. ~1.6e-3 sqrt(d) standard deviations of a gaussian score
+//           distribution): kc = k + max(44, k max(0.6, 0.022 sqrt(d))).  Queries without a proof are
+//           searched again in mode 1 (as one smaller batch), or by the exact kernel if they are few.
+//   mode 1: x_hi q_hi + x_hi q_lo + x_lo q_hi, error <= 2e-4 |q||x|: kc = k + max(28, k/8); queries without a
+//           proof (near-ties inside that bound, non-finite rows) go to the exact kernel.
+// A corpus on which mode 2 fails for more than a quarter of a batch starts with mode 1 from then on.
+int split_kc(int k, int mode, int d) {
+    if (mode != 2) return k + std::max(28, k / 8);
+    const double frac = std::max(0.6, 0.022 * std::sqrt((double)d));
+    return k + std::max(44, (int)std::ceil(k * frac));
+}
+
+int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st,
+                       int mode) {
+    const int kc = split_kc(k, mode, ix->d);
     const long long nq_pad = round_up64(nq, S16_BQ);
     const int S2 = (kc + k - 1) / k;
     int rc;
     if ((rc = ix->qs.reserve((size_t)nq_pad * ix->ld * 4))) return rc;
     if ((rc = ix->qnorm2.reserve((size_t)nq_pad * sizeof(float)))) return rc;
+    if ((rc = ix->qres2.reserve((size_t)nq_pad * sizeof(float)))) return rc;
     if ((rc = ix->qpad.reserve((size_t)nq_pad * ix->ld * sizeof(float)))) return rc;
     if ((rc = ix->cD.reserve((size_t)nq * kc * sizeof(float)))) return rc;
     if ((rc = ix->cI.reserve((size_t)nq * kc * sizeof(long long)))) return rc;
@@ -1601,15 +1636,18 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, in
     if ((rc = ix->flags.reserve((size_t)(nq + 1) * sizeof(u32)))) return rc;
     hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)std::min<long long>((nq_pad + 3) / 4, 16384)), dim3(256), 0, st,
                        qd, (long long)ix->d, (unsigned short*)ix->qs.p, nq, nq_pad, ix->d, ix->ld, (float*)ix->qnorm2.p,
-                       0ll);
+                       0ll, (float*)ix->qres2.p);
     {
         const long long total = nq_pad * ix->ld;
         hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0,
                            st, qd, (float*)ix->qpad.p, nq, nq_pad, ix->d, ix->ld);
     }
     OTTER_HIP_TRY(hipGetLastError());
-    if ((rc = scan16_and_merge<1>(ix, ix->xs.p, 2 * ix->ld, nq, kc, (float*)ix->cD.p, (long long*)ix->cI.p, st)))
-        return rc;
+    if (mode == 2)
+        rc = scan16_and_merge<2>(ix, ix->xs.p, 2 * ix->ld, nq, kc, (float*)ix->cD.p, (long long*)ix->cI.p, st);
+    else
+        rc = scan16_and_merge<1>(ix, ix->xs.p, 2 * ix->ld, nq, kc, (float*)ix->cD.p, (long long*)ix->cI.p, st);
+    if (rc) return rc;
     RescoreArgs ra;
     ra.X = ix->x;
     ra.Q = (const float*)ix->qpad.p;
@@ -1630,35 +1668,48 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, in
     OTTER_HIP_TRY(hipMemsetAsync(flags + nq, 0, sizeof(u32), st));
     hipLaunchKernelGGL(margin_check_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (const float*)D,
                        (const float*)ix->cD.p, (const long long*)ix->cI.p, (const float*)ix->qnorm2.p,
-                       (const u32*)ix->xnmax.p, split_rel_eps(ix->d), nq, k, kc, ix->n, flags, flags + nq);
+                       (const u32*)ix->xnmax.p, split_rel_eps(ix->d), nq, k, kc, ix->n, flags, flags + nq,
+                       mode == 2 ? (const float*)ix->qres2.p : (const float*)nullptr);
     OTTER_HIP_TRY(hipGetLastError());
-    // the one host round trip of this path: how many queries are left without a proof
+    // the one host round trip of this pass: how many queries are left without a proof
     std::vector<u32> hflags((size_t)nq + 1);
     OTTER_HIP_TRY(hipMemcpyAsync(hflags.data(), flags, (size_t)(nq + 1) * sizeof(u32), hipMemcpyDeviceToHost, st));
     OTTER_HIP_TRY(hipStreamSynchronize(st));
     const long long nf = hflags[(size_t)nq];
-    ix->last_fallback = nf;
+    if (mode == 2) {
+        ix->last_refined = nf;
+        if (nf * 4 > nq) ix->two_prod_off = true;
+    } else {
+        ix->last_fallback = nf;
+    }
     if (nf == 0) return OTTER_OK;
-    // unproven queries: gather them, run the exact kernel, scatter the rows back
-    if ((rc = ix->fb_q.reserve((size_t)nf * ix->d * sizeof(float)))) return rc;
-    if ((rc = ix->fb_D.reserve((size_t)nf * k * sizeof(float)))) return rc;
-    if ((rc = ix->fb_I.reserve((size_t)nf * k * sizeof(long long)))) return rc;
+    // unproven queries: gather them, search them again one level down, scatter the rows back
+    otter::DevBuf& bq = mode == 2 ? ix->fb2_q : ix->fb_q;
+    otter::DevBuf& bD = mode == 2 ? ix->fb2_D : ix->fb_D;
+    otter::DevBuf& bI = mode == 2 ? ix->fb2_I : ix->fb_I;
+    if ((rc = bq.reserve((size_t)nf * ix->d * sizeof(float)))) return rc;
+    if ((rc = bD.reserve((size_t)nf * k * sizeof(float)))) return rc;
+    if ((rc = bI.reserve((size_t)nf * k * sizeof(long long)))) return rc;
     std::vector<long long> which;
     for (long long q = 0; q < nq; ++q)
         if (hflags[(size_t)q]) which.push_back(q);
     for (size_t i = 0; i < which.size(); ++i)
-        OTTER_HIP_TRY(hipMemcpyAsync((float*)ix->fb_q.p + i * ix->d, qd + (size_t)which[i] * ix->d,
+        OTTER_HIP_TRY(hipMemcpyAsync((float*)bq.p + i * ix->d, qd + (size_t)which[i] * ix->d,
                                      (size_t)ix->d * sizeof(float), hipMemcpyDeviceToDevice, st));
-    ix->no_split = true;
-    rc = search_chunk(ix, (const float*)ix->fb_q.p, (long long)which.size(), k, (float*)ix->fb_D.p,
-                      (long long*)ix->fb_I.p, st);
-    ix->no_split = false;
+    if (mode == 2 && nf >= 65) {
+        rc = search_chunk_split(ix, (const float*)bq.p, nf, k, (float*)bD.p, (long long*)bI.p, st, 1);
+    } else {
+        if (mode == 2) ix->last_fallback = nf;
+        ix->no_split = true;
+        rc = search_chunk(ix, (const float*)bq.p, nf, k, (float*)bD.p, (long long*)bI.p, st);
+        ix->no_split = false;
+    }
     if (rc) return rc;
     for (size_t i = 0; i < which.size(); ++i) {
-        OTTER_HIP_TRY(hipMemcpyAsync(D + (size_t)which[i] * k, (float*)ix->fb_D.p + i * k, (size_t)k * sizeof(float),
+        OTTER_HIP_TRY(hipMemcpyAsync(D + (size_t)which[i] * k, (float*)bD.p + i * k, (size_t)k * sizeof(float),
                                      hipMemcpyDeviceToDevice, st));
-        OTTER_HIP_TRY(hipMemcpyAsync(I + (size_t)which[i] * k, (long long*)ix->fb_I.p + i * k,
-                                     (size_t)k * sizeof(long long), hipMemcpyDeviceToDevice, st));
+        OTTER_HIP_TRY(hipMemcpyAsync(I + (size_t)which[i] * k, (long long*)bI.p + i * k, (size_t)k * sizeof(long long),
+                                     hipMemcpyDeviceToDevice, st));
     }
     return OTTER_OK;
 }
@@ -1934,6 +1985,7 @@ int otter_index_reset(otter_index* ix) {
     if (!ix) return set_err(OTTER_EINVAL, "reset: index is NULL");
     ix->n = 0;
     ix->xs_rows = 0;
+    ix->two_prod_off = false;
     if (ix->xnmax.p) {
         DeviceGuard g(ix->device);
         OTTER_HIP_TRY(hipMemset(ix->xnmax.p, 0, sizeof(u32)));
@@ -1972,6 +2024,7 @@ int otter_index_timing(otter_index* ix, double* scan_ms, int64_t* scan_launches)
 }
 
 int64_t otter_index_last_fallback(const otter_index* ix) { return ix ? ix->last_fallback : -1; }
+int64_t otter_index_last_refined(const otter_index* ix) { return ix ? ix->last_refined : -1; }
 
 void otter_index_destroy(otter_index* ix) {
     if (!ix) return;
@@ -1981,7 +2034,7 @@ void otter_index_destroy(otter_index* ix) {
     if (ix->x) (void)hipFree(ix->x);
     if (ix->x16) (void)hipFree(ix->x16);
     for (otter::DevBuf* b : {&ix->xs, &ix->xnorm2, &ix->xnmax, &ix->qs, &ix->qnorm2, &ix->cD, &ix->cI, &ix->rs,
-                             &ix->rscnt, &ix->flags, &ix->fb_q, &ix->fb_D, &ix->fb_I})
+                             &ix->rscnt, &ix->flags, &ix->fb_q, &ix->fb_D, &ix->fb_I, &ix->qres2, &ix->fb2_q, &ix->fb2_D, &ix->fb2_I})
         b->release();
     ix->qpad.release();
     ix->cand.release();

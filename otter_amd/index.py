@@ -202,6 +202,11 @@ class IndexFlatIP:
         """Queries of the last search() that the coarse bf16 pass could not prove and the exact kernel re-did."""
         return int(self._lib.otter_index_last_fallback(self._h))
 
+    @property
+    def last_refined(self):
+        """Queries of the last search() that the two-product coarse pass left unproven (searched again)."""
+        return int(self._lib.otter_index_last_refined(self._h))
+
     def reset(self):
         _lib.check(self._lib.otter_index_reset(self._h), "otter_index_reset")
 

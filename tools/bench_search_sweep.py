@@ -72,7 +72,7 @@ def main():
                "GBps": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM, 4), "TFLOPs": round(tf, 2),
                "mfma_frac": round(tf / (2500.0 if a.dtype == "bf16" else PEAK_F32), 4),
                "queries_per_s": round(nq / (wall * 1e-3), 1),
-               "dtype": a.dtype, "fallback_queries": ix.last_fallback}
+               "dtype": a.dtype, "fallback_queries": ix.last_fallback, "refined_queries": ix.last_refined}
         if ref is not None:
             _, I16 = ix.search(q, a.k)
             _, I32 = ref.search(q, a.k)
