@@ -64,6 +64,37 @@ def test_split_path_falls_back_on_near_ties_and_stays_exact():
     assert fb > 0, "this corpus is built to defeat the margin proof"
 
 
+def test_two_product_pass_hands_over_to_the_three_product_pass():
+    # clusters whose members differ by ~6 score units: too close for the two-product pass's bound
+    # (|q - q_hi| max|x| ~ 1.3) to prove the top 100 with 60 spare candidates, far enough apart for the
+    # three-product bound (~0.15).  All 200 queries are searched again by the three-product pass, none by the
+    # exact kernel; the corpus then starts with three products until reset().
+    from otter_amd.index import IndexFlatIP
+    rng = np.random.RandomState(5)
+    n, d, nq, k = 70000, 768, 200, 100
+    proto = rng.randn(40, d).astype(np.float32)
+    xb = (proto[rng.randint(0, 40, size=n)] + 0.22 * rng.randn(n, d)).astype(np.float32)
+    q = rng.randn(nq, d).astype(np.float32)
+    Dr, Ir = flat_ip.search_c(xb, q, k, mode=flat_ip.MODE_GPU_ORDER)
+    ix = IndexFlatIP(d)
+    ix.add(xb)
+    D, I = ix.search(q, k)
+    refined, fb = ix.last_refined, ix.last_fallback
+    np.testing.assert_array_equal(I, Ir)
+    np.testing.assert_array_equal(D.view(np.uint32), Dr.view(np.uint32))
+    assert refined > nq // 2, "built to defeat the two-product proof (%d of %d refined)" % (refined, nq)
+    assert fb <= nq // 10, "the three-product pass should prove these (%d to the exact kernel)" % fb
+    D2, I2 = ix.search(q, k)                                 # sticky: straight to three products
+    assert ix.last_refined == 0
+    np.testing.assert_array_equal(I2, Ir)
+    np.testing.assert_array_equal(D2.view(np.uint32), Dr.view(np.uint32))
+    ix.reset()
+    ix.add(rng.randn(n, d).astype(np.float32))              # a friendly corpus again: two products suffice
+    ix.search(q, k)
+    assert ix.last_refined <= 2 and ix.last_fallback <= 2
+    ix.close()
+
+
 def test_split_path_non_finite_rows_and_incremental_add():
     from otter_amd.index import IndexFlatIP
     xb, q = _mk(90000, 128, 220, seed=21)
