@@ -116,24 +116,47 @@ __device__ __forceinline__ u64 stamp() {
 // One wavefront selects the k largest of the n (<= 64*EPL) composites at `base`,
 // moves them to base[0..k) and returns the k-th largest.  Radix select, one bit
 // per round, counted with ballots; composites are unique so exactly k survive.
+// The score keys (high words) are selected first with 32-bit compares -- they are almost always
+// distinct, so the rounds end there; only entries that tie the k-th key go on to the row words.
 template <int EPL>
-__device__ __forceinline__ u64 wave_compact(u64* base, int n, int k, int lane) {
-    u64 x[EPL];
+__device__ __forceinline__ void wave_compact_load(u64 (&x)[EPL], const u64* base, int n, int lane) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         int idx = e * 64 + lane;
         // agent-scope load: bypass this CU's vector L1 (entries were stored by other waves)
         x[e] = idx < n ? __hip_atomic_load(base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     }
-    u64 T = 0;
-    for (int b = 63; b >= 0; --b) {
-        const u64 c = T | (1ull << b);
+}
+
+template <int EPL>
+__device__ __forceinline__ u64 wave_compact_select(u64 (&x)[EPL], u64* base, int k, int lane) {
+    u32 Th = 0;
+    bool exact = false;          // exactly k entries have a key >= Th
+    for (int b = 31; b >= 0; --b) {
+        const u32 c = Th | (1u << b);
         int cntv = 0;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) cntv += __popcll(__ballot(x[e] >= c));
-        if (cntv >= k) T = c;
-        if (cntv == k) break;   // exactly k composites are >= T: T selects the same set as the k-th largest
+        for (int e = 0; e < EPL; ++e) cntv += __popcll(__ballot((u32)(x[e] >> 32) >= c));
+        if (cntv >= k) Th = c;
+        if (cntv == k) { exact = true; break; }
     }
+    u32 Tl = 0;
+    if (!exact) {
+        // more than k entries reach key Th: all with a larger key stay, the ties compete on the row word
+        int above = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) above += __popcll(__ballot((u32)(x[e] >> 32) > Th));
+        const int need = k - above;
+        for (int b = 31; b >= 0; --b) {
+            const u32 c = Tl | (1u << b);
+            int cntv = 0;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) cntv += __popcll(__ballot((u32)(x[e] >> 32) == Th && (u32)x[e] >= c));
+            if (cntv >= need) Tl = c;
+            if (cntv == need) break;
+        }
+    }
+    const u64 T = ((u64)Th << 32) | Tl;
     int off = 0;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
@@ -144,6 +167,13 @@ __device__ __forceinline__ u64 wave_compact(u64* base, int n, int k, int lane) {
         off += __popcll(m);
     }
     return T;
+}
+
+template <int EPL>
+__device__ __forceinline__ u64 wave_compact(u64* base, int n, int k, int lane) {
+    u64 x[EPL];
+    wave_compact_load<EPL>(x, base, n, lane);
+    return wave_compact_select<EPL>(x, base, k, lane);
 }
 
 // WM x WQ waves; each wave owns (MB*32) corpus rows x (QB*32) queries of the tile.
@@ -632,22 +662,46 @@ __global__ __launch_bounds__(512, 2) void scan16_kernel(Scan16Args a) {
                         }
                     }
                 }
-                acc[m][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
+    };
+    // (the accumulators are cleared after a possible compaction, not in the epilogue: 128 registers that
+    // are dead while the compaction runs)
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) acc[m][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     auto compact_pass = [&](bool final_pass) {
         wait_vmcnt<0>();
         wg_barrier();
+        // a compaction is one dependent round trip to L2 (the entries) followed by the select: the next
+        // query's entries are requested before the current query's select runs
+        u64 xc[EPL];
+        int qc = -1;
         for (int q = wave; q < S16_BQ; q += 8) {
             const int n = (int)sCnt[q];
             const bool need = final_pass ? (n > a.k) : (n > CAP - S16_BM);
-            if (need) {
-                const u64 T = wave_compact<EPL>(candBase + (size_t)q * CAP, n, a.k, lane);
+            if (!need) continue;
+            u64 xn[EPL];
+            wave_compact_load<EPL>(xn, candBase + (size_t)q * CAP, n, lane);
+            if (qc >= 0) {
+                const u64 T = wave_compact_select<EPL>(xc, candBase + (size_t)qc * CAP, a.k, lane);
                 if (lane == 0) {
-                    sCnt[q] = (u32)a.k;
-                    sThr[q] = (u32)(T >> 32);
+                    sCnt[qc] = (u32)a.k;
+                    sThr[qc] = (u32)(T >> 32);
                 }
+            }
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) xc[e] = xn[e];
+            qc = q;
+        }
+        if (qc >= 0) {
+            const u64 T = wave_compact_select<EPL>(xc, candBase + (size_t)qc * CAP, a.k, lane);
+            if (lane == 0) {
+                sCnt[qc] = (u32)a.k;
+                sThr[qc] = (u32)(T >> 32);
             }
         }
         if (tid == 0) *sFlag = 0;
@@ -696,6 +750,7 @@ __global__ __launch_bounds__(512, 2) void scan16_kernel(Scan16Args a) {
                     wg_barrier();        // group 0 waits for group 1: every wave is past its epilogue
                 }
                 if (__builtin_amdgcn_readfirstlane(*sFlag)) compact_pass(false);   // same barriers for all waves
+                zero_acc();
                 ++c_tile;
                 if (g == 1 && cs + 1 < total_stages) bar();   // fall one barrier behind again
             } else {
@@ -764,6 +819,25 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
             for (int o = 32; o > 0; o >>= 1) rr += __shfl_xor(rr, o);
             if (lane == 0) res2[r] = rr;
         }
+    }
+}
+
+// |row - bf16(row)|^2 of fp32 rows [rows][ld] (one wave per row): what a product on rounded rows leaves out
+__global__ __launch_bounds__(256) void residual_norm_kernel(const float* __restrict__ src, long long rows, int ld,
+                                                            float* __restrict__ res2) {
+    const int lane = threadIdx.x & 63;
+    const long long w0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long r = w0; r < rows; r += nw) {
+        float rr = 0.f;
+        for (int c = lane; c < ld; c += 64) {
+            const float v = src[r * ld + c];
+            const float e = v - (float)(__bf16)v;
+            rr += e * e;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) rr += __shfl_xor(rr, o);
+        if (lane == 0) res2[r] = rr;
     }
 }
 
@@ -862,7 +936,8 @@ __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
 // qres2 (two-product coarse pass): |q - q_hi|^2; that pass leaves out x . (q - q_hi), at most |q - q_hi| |x|.
 __global__ void margin_check_kernel(const float* Dexact, const float* Dcoarse, const long long* Icoarse,
                                     const float* qnorm2, const u32* xnorm2_max, float rel, long long nq, int k, int kc,
-                                    long long n, u32* flags, u32* nflag, const float* qres2) {
+                                    long long n, u32* flags, u32* nflag, const float* qres2,
+                                    const u32* xres2_max) {
     const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (q >= nq) return;
     bool ok;
@@ -874,6 +949,8 @@ __global__ void margin_check_kernel(const float* Dexact, const float* Dcoarse, c
         const float xmax = sqrtf(__uint_as_float(*xnorm2_max));
         float eps = rel * sqrtf(qnorm2[q]) * xmax;
         if (qres2) eps += 1.001f * sqrtf(qres2[q]) * xmax;
+        // one product: q.x - q_hi.x_hi = (q - q_hi).x + q_hi.(x - x_hi), |q_hi| <= (1 + 2^-8) |q|
+        if (xres2_max) eps += 1.005f * sqrtf(qnorm2[q]) * sqrtf(__uint_as_float(*xres2_max));
         ok = Icoarse[q * kc + kc - 1] >= 0 && ek > tc + eps;    // false on NaN / inf bounds
     }
     flags[q] = ok ? 0u : 1u;
@@ -1184,6 +1261,7 @@ constexpr int S16_MAX_K = 1280;   // (1280: top-1000 of an fp32 index plus its c
 template <int MODE>
 int pick_cfg16(int k, Scan16Cfg* out) {
     if (k <= 160) *out = Scan16Cfg{8 * 64, &launch_scan16<MODE, 8>};   // 512 slots: kk + a 256-row tile fit
+    else if (k <= 320) *out = Scan16Cfg{12 * 64, &launch_scan16<MODE, 12>};
     else if (k <= 512) *out = Scan16Cfg{20 * 64, &launch_scan16<MODE, 20>};
     else if (k <= S16_MAX_K) *out = Scan16Cfg{36 * 64, &launch_scan16<MODE, 36>};
     else return set_err(OTTER_EINVAL, "search: k=%d exceeds %d, the bound of the bf16 scan", k, S16_MAX_K);
@@ -1212,6 +1290,12 @@ struct otter_index {
     long long last_refined = 0;     // ... that the two-product pass could not prove (three-product pass or exact kernel)
     bool two_prod_off = false;      // the two-product pass failed for > 1/4 of a batch: this corpus starts with three
     otter::DevBuf qres2, fb2_q, fb2_D, fb2_I;
+    // one-product pass (stage 0): a third copy of the corpus, bf16 hi values only (half the fp32 bytes), the
+    // largest |x - x_hi| over its rows for the error bound, and the rounded queries
+    otter::DevBuf xh, xres2, xrmax, qh16, fb3_q, fb3_D, fb3_I;
+    long long xh_rows = 0, xh_cap = 0;
+    bool xh_failed = false, one_prod_off = false;
+    long long last_stage0_unproven = 0;
     otter::DevBuf qs, qnorm2, cD, cI, rs, rscnt, flags, fb_q, fb_D, fb_I;
     otter::DevBuf qpad, cand, cnt, lvl[2], lvlcnt[2], smp, smpcnt, thr0, io_q, io_D, io_I;
     bool timing = false;
@@ -1319,9 +1403,10 @@ int run_merge(otter_index* ix, const u64* in, const u32* in_cnt, int cap_in, int
 
 int search_chunk_bf16(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st);
 int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st,
-                       int mode);
+                       int mode, bool first);
 int split_kc(int k, int mode, int d);
 int ensure_split_planes(otter_index* ix, hipStream_t st);
+int ensure_hi_plane(otter_index* ix, hipStream_t st);
 
 // one scan + merge over queries [qd, qd + nq) (device pointers), results to device D/I
 int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st) {
@@ -1336,10 +1421,17 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
             const int rs = ensure_split_planes(ix, st);
             if (rs < 0) return rs;
             if (rs == 0) {
-                const bool two = !(mode_env && mode_env[0] == '1') && !ix->two_prod_off && split_kc(k, 2, ix->d) <= S16_MAX_K;
+                const int forced = mode_env ? atoi(mode_env) : 0;      // 1 / 2: start with that many products
+                int mode = 1;
+                if (forced != 1 && !ix->two_prod_off && split_kc(k, 2, ix->d) <= S16_MAX_K) mode = 2;
+                if (forced != 1 && forced != 2 && !ix->one_prod_off && split_kc(k, 3, ix->d) <= S16_MAX_K) {
+                    const int rh = ensure_hi_plane(ix, st);
+                    if (rh < 0) return rh;
+                    if (rh == 0) mode = 3;
+                }
                 ix->last_fallback = 0;
                 ix->last_refined = 0;
-                return search_chunk_split(ix, qd, nq, k, D, I, st, two ? 2 : 1);
+                return search_chunk_split(ix, qd, nq, k, D, I, st, mode, true);
             }
         }
     }
@@ -1468,7 +1560,7 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
 // so a later row that only ties that key ranks behind kk sample rows.
 template <int MODE>
 int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int kk, float* Dc, long long* Ic,
-                     hipStream_t st) {
+                     hipStream_t st, const void* Qk = nullptr) {
     Scan16Cfg cfg;
     int rc = pick_cfg16<MODE>(kk, &cfg);
     if (rc) return rc;
@@ -1498,7 +1590,7 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
     }
     Scan16Args sa;
     sa.X = (const char*)Xk;
-    sa.Q = (const char*)ix->qs.p;
+    sa.Q = Qk ? (const char*)Qk : (const char*)ix->qs.p;
     sa.cand = (u64*)ix->cand.p;
     sa.cnt = (u32*)ix->cnt.p;
     sa.n = ix->n;
@@ -1601,26 +1693,70 @@ int ensure_split_planes(otter_index* ix, hipStream_t st) {
     return OTTER_OK;
 }
 
+// stage 0's corpus copy: bf16(x) rows in the bf16 index's tile-blocked plane format + max |x - bf16(x)|^2.
+// 0: ready, 1: not available (no HBM for it), < 0: error
+int ensure_hi_plane(otter_index* ix, hipStream_t st) {
+    if (ix->xh_failed) return 1;
+    int rc;
+    if (ix->xh_cap < ix->cap_rows) {
+        ix->xh.release();
+        ix->xh_rows = 0;
+        ix->xh_cap = 0;
+        hipError_t e = hipMalloc(&ix->xh.p, (size_t)ix->cap_rows * ix->ld * 2);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            ix->xh.p = nullptr;
+            ix->xh_failed = true;
+            return 1;
+        }
+        ix->xh.bytes = (size_t)ix->cap_rows * ix->ld * 2;
+        OTTER_HIP_TRY(hipMemsetAsync(ix->xh.p, 0, ix->xh.bytes, st));
+        if ((rc = ix->xres2.reserve((size_t)ix->cap_rows * sizeof(float)))) return rc;
+        if ((rc = ix->xrmax.reserve(sizeof(u32)))) return rc;
+        OTTER_HIP_TRY(hipMemsetAsync(ix->xrmax.p, 0, sizeof(u32), st));
+        ix->xh_cap = ix->cap_rows;
+    }
+    if (ix->xh_rows < ix->n) {
+        const long long lo = ix->xh_rows, rows = ix->n - lo;
+        const long long total = rows * ix->ld;
+        hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 8192)), dim3(256), 0,
+                           st, (const float*)ix->x + (size_t)lo * ix->ld, (unsigned short*)ix->xh.p, rows, rows, ix->ld,
+                           ix->ld, lo);
+        hipLaunchKernelGGL(residual_norm_kernel, dim3((unsigned)std::min<long long>((rows + 3) / 4, 16384)), dim3(256), 0, st,
+                           (const float*)ix->x + (size_t)lo * ix->ld, rows, ix->ld, (float*)ix->xres2.p + lo);
+        hipLaunchKernelGGL(max_norm_kernel, dim3((unsigned)std::min<long long>((rows + 255) / 256, 1024)), dim3(256), 0,
+                           st, (const float*)ix->xres2.p + lo, rows, (u32*)ix->xrmax.p);
+        OTTER_HIP_TRY(hipGetLastError());
+        ix->xh_rows = ix->n;
+    }
+    return OTTER_OK;
+}
+
 int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st);
 
 // Exact fp32 search of a large query batch through the bf16 matrix cores: coarse top-kc on hi/lo bf16
 // planes, exact re-scoring of those candidates with scan_kernel's fp32 chain, and a per-query proof that
 // no other row can reach the top k.  Results are identical to search_chunk's.
+//   mode 3: coarse score x_hi q_hi alone (one product, on a third copy of the corpus that holds bf16(x) only --
+//           skipped when HBM has no room for it).  q.x - q_hi.x_hi = (q - q_hi).x + q_hi.(x - x_hi), at most
+//           |q - q_hi| max|x| + |q| max|x - x_hi|: kc = k + max(60, k max(1, 0.04 sqrt(d))).  Unproven queries
+//           are searched again in mode 2.
 //   mode 2: coarse score x_hi q_hi + x_lo q_hi (two products).  Left out: x . (q - q_hi), at most
 //           |q - q_hi| max|x| (~1.6e-3 |q||x|, i.e. ~1.6e-3 sqrt(d) standard deviations of a gaussian score
 //           distribution): kc = k + max(44, k max(0.6, 0.022 sqrt(d))).  Queries without a proof are
 //           searched again in mode 1 (as one smaller batch), or by the exact kernel if they are few.
 //   mode 1: x_hi q_hi + x_hi q_lo + x_lo q_hi, error <= 2e-4 |q||x|: kc = k + max(28, k/8); queries without a
 //           proof (near-ties inside that bound, non-finite rows) go to the exact kernel.
-// A corpus on which mode 2 fails for more than a quarter of a batch starts with mode 1 from then on.
+// A corpus on which a mode fails for more than a quarter of a batch starts one mode further down from then on.
 int split_kc(int k, int mode, int d) {
-    if (mode != 2) return k + std::max(28, k / 8);
-    const double frac = std::max(0.6, 0.022 * std::sqrt((double)d));
-    return k + std::max(44, (int)std::ceil(k * frac));
+    if (mode == 1) return k + std::max(28, k / 8);
+    const double sd = std::sqrt((double)d);
+    if (mode == 2) return k + std::max(44, (int)std::ceil(k * std::max(0.6, 0.022 * sd)));
+    return k + std::max(60, (int)std::ceil(k * std::max(1.0, 0.04 * sd)));   // mode 3: twice mode 2's bound
 }
 
 int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st,
-                       int mode) {
+                       int mode, bool first) {
     const int kc = split_kc(k, mode, ix->d);
     const long long nq_pad = round_up64(nq, S16_BQ);
     const int S2 = (kc + k - 1) / k;
@@ -1643,7 +1779,14 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
                            st, qd, (float*)ix->qpad.p, nq, nq_pad, ix->d, ix->ld);
     }
     OTTER_HIP_TRY(hipGetLastError());
-    if (mode == 2)
+    if (mode == 3) {
+        if ((rc = ix->qh16.reserve((size_t)nq_pad * ix->ld * 2))) return rc;
+        const long long total = nq_pad * ix->ld;
+        hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0,
+                           st, qd, (unsigned short*)ix->qh16.p, nq, nq_pad, ix->d, ix->ld, 0ll);
+        OTTER_HIP_TRY(hipGetLastError());
+        rc = scan16_and_merge<0>(ix, ix->xh.p, ix->ld, nq, kc, (float*)ix->cD.p, (long long*)ix->cI.p, st, ix->qh16.p);
+    } else if (mode == 2)
         rc = scan16_and_merge<2>(ix, ix->xs.p, 2 * ix->ld, nq, kc, (float*)ix->cD.p, (long long*)ix->cI.p, st);
     else
         rc = scan16_and_merge<1>(ix, ix->xs.p, 2 * ix->ld, nq, kc, (float*)ix->cD.p, (long long*)ix->cI.p, st);
@@ -1669,24 +1812,23 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
     hipLaunchKernelGGL(margin_check_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (const float*)D,
                        (const float*)ix->cD.p, (const long long*)ix->cI.p, (const float*)ix->qnorm2.p,
                        (const u32*)ix->xnmax.p, split_rel_eps(ix->d), nq, k, kc, ix->n, flags, flags + nq,
-                       mode == 2 ? (const float*)ix->qres2.p : (const float*)nullptr);
+                       mode >= 2 ? (const float*)ix->qres2.p : (const float*)nullptr,
+                       mode == 3 ? (const u32*)ix->xrmax.p : (const u32*)nullptr);
     OTTER_HIP_TRY(hipGetLastError());
     // the one host round trip of this pass: how many queries are left without a proof
     std::vector<u32> hflags((size_t)nq + 1);
     OTTER_HIP_TRY(hipMemcpyAsync(hflags.data(), flags, (size_t)(nq + 1) * sizeof(u32), hipMemcpyDeviceToHost, st));
     OTTER_HIP_TRY(hipStreamSynchronize(st));
     const long long nf = hflags[(size_t)nq];
-    if (mode == 2) {
-        ix->last_refined = nf;
-        if (nf * 4 > nq) ix->two_prod_off = true;
-    } else {
-        ix->last_fallback = nf;
-    }
+    if (mode >= 2 && first) ix->last_refined = nf;
+    if (mode == 3 && nf * 4 > nq) ix->one_prod_off = true;
+    if (mode == 2 && nf * 4 > nq) ix->two_prod_off = true;
+    if (mode == 1) ix->last_fallback = nf;
     if (nf == 0) return OTTER_OK;
     // unproven queries: gather them, search them again one level down, scatter the rows back
-    otter::DevBuf& bq = mode == 2 ? ix->fb2_q : ix->fb_q;
-    otter::DevBuf& bD = mode == 2 ? ix->fb2_D : ix->fb_D;
-    otter::DevBuf& bI = mode == 2 ? ix->fb2_I : ix->fb_I;
+    otter::DevBuf& bq = mode == 3 ? ix->fb3_q : mode == 2 ? ix->fb2_q : ix->fb_q;
+    otter::DevBuf& bD = mode == 3 ? ix->fb3_D : mode == 2 ? ix->fb2_D : ix->fb_D;
+    otter::DevBuf& bI = mode == 3 ? ix->fb3_I : mode == 2 ? ix->fb2_I : ix->fb_I;
     if ((rc = bq.reserve((size_t)nf * ix->d * sizeof(float)))) return rc;
     if ((rc = bD.reserve((size_t)nf * k * sizeof(float)))) return rc;
     if ((rc = bI.reserve((size_t)nf * k * sizeof(long long)))) return rc;
@@ -1696,10 +1838,11 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
     for (size_t i = 0; i < which.size(); ++i)
         OTTER_HIP_TRY(hipMemcpyAsync((float*)bq.p + i * ix->d, qd + (size_t)which[i] * ix->d,
                                      (size_t)ix->d * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (mode == 2 && nf >= 65) {
-        rc = search_chunk_split(ix, (const float*)bq.p, nf, k, (float*)bD.p, (long long*)bI.p, st, 1);
+    if (mode >= 2 && nf >= 65) {
+        const int next = (mode == 3 && !ix->two_prod_off && split_kc(k, 2, ix->d) <= S16_MAX_K) ? 2 : 1;
+        rc = search_chunk_split(ix, (const float*)bq.p, nf, k, (float*)bD.p, (long long*)bI.p, st, next, false);
     } else {
-        if (mode == 2) ix->last_fallback = nf;
+        if (mode >= 2) ix->last_fallback = nf;
         ix->no_split = true;
         rc = search_chunk(ix, (const float*)bq.p, nf, k, (float*)bD.p, (long long*)bI.p, st);
         ix->no_split = false;
@@ -1986,6 +2129,12 @@ int otter_index_reset(otter_index* ix) {
     ix->n = 0;
     ix->xs_rows = 0;
     ix->two_prod_off = false;
+    ix->one_prod_off = false;
+    ix->xh_rows = 0;
+    if (ix->xrmax.p) {
+        DeviceGuard g2(ix->device);
+        OTTER_HIP_TRY(hipMemset(ix->xrmax.p, 0, sizeof(u32)));
+    }
     if (ix->xnmax.p) {
         DeviceGuard g(ix->device);
         OTTER_HIP_TRY(hipMemset(ix->xnmax.p, 0, sizeof(u32)));
@@ -2034,7 +2183,8 @@ void otter_index_destroy(otter_index* ix) {
     if (ix->x) (void)hipFree(ix->x);
     if (ix->x16) (void)hipFree(ix->x16);
     for (otter::DevBuf* b : {&ix->xs, &ix->xnorm2, &ix->xnmax, &ix->qs, &ix->qnorm2, &ix->cD, &ix->cI, &ix->rs,
-                             &ix->rscnt, &ix->flags, &ix->fb_q, &ix->fb_D, &ix->fb_I, &ix->qres2, &ix->fb2_q, &ix->fb2_D, &ix->fb2_I})
+                             &ix->rscnt, &ix->flags, &ix->fb_q, &ix->fb_D, &ix->fb_I, &ix->qres2, &ix->fb2_q, &ix->fb2_D, &ix->fb2_I, &ix->xh, &ix->xres2, &ix->xrmax, &ix->qh16,
+                             &ix->fb3_q, &ix->fb3_D, &ix->fb3_I})
         b->release();
     ix->qpad.release();
     ix->cand.release();
