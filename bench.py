@@ -334,13 +334,14 @@ def main():
         kern_ms = scan_ms / max(launches, 1)
         flops = 2.0 * n * d * nq
         split = nq >= 65 and n >= 65536 and not os.environ.get("OTTER_NO_SPLIT")
-        two = os.environ.get("OTTER_SPLIT_MODE") != "1"
-        if split:   # coarse pass on bf16 hi/lo planes: 2 (default) or 3 MFMA products per term
-            kernel_flops, peak = (2.0 if two else 3.0) * flops, PEAK_BF16_MFMA_TFLOPS
-            kname = ("scan16_kernel<%d,8> (256x256 tile, v_mfma_f32_16x16x32_bf16 on hi/lo bf16 planes of the fp32 "
+        nprod = {"1": 3, "2": 2}.get(os.environ.get("OTTER_SPLIT_MODE", ""), 1)
+        if split:   # coarse pass on bf16 planes of the fp32 operands: 1 (default), 2 or 3 MFMA products per term
+            kernel_flops, peak = float(nprod) * flops, PEAK_BF16_MFMA_TFLOPS
+            kname = ("scan16_kernel<%d,*> (256x256 tile, v_mfma_f32_16x16x32_bf16 on bf16 planes of the fp32 "
                      "operands: %s, fused top-k filter; then exact fp32 re-scoring + margin proof; unproven queries "
-                     "go to the three-product pass / the exact kernel). " % (2 if two else 1,
-                     "x_hi*q_hi + x_lo*q_hi" if two else "x_hi*q_hi + x_hi*q_lo + x_lo*q_hi") +
+                     "go to the pass with one more product / the exact kernel). " % (
+                         {1: 0, 2: 2, 3: 1}[nprod],
+                         {1: "x_hi*q_hi", 2: "x_hi*q_hi + x_lo*q_hi", 3: "x_hi*q_hi + x_hi*q_lo + x_lo*q_hi"}[nprod]) +
                      "kernel_ms is one HIP-event bracket per search on the launch stream = TWO dispatches of this kernel "
                      "(threshold-seeding sample pass over the first tiles, then the main scan) and the ~0.12 ms merge "
                      "between them: rocprof's TotalDurationNs of scan16_kernel / steps + that merge")
