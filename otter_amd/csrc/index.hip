@@ -985,7 +985,8 @@ struct MergeArgs {
     int k;
     int npad;            // power of two >= fan * min(cap_in, k) (+ k with an extra list)
     int final_level;
-    const u64* ex;       // final level only: one more sorted list [nq_pad][k] (the sample pass), or null
+    const u64* ex;       // last level only: one more sorted list [nq_pad][k] (the sample passes so far), or null;
+                         // may alias `out` (a workgroup has gathered its query's lists before it writes)
     const u32* ex_cnt;   // [nq_pad]
     u32* thr_out;        // non-final level with one group: [nq_pad] key of the k-th best, 0 if fewer than k
 };
@@ -1022,7 +1023,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(MergeArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s0 = g * a.fan;
     const int ns = min(a.S_in, s0 + a.fan) - s0;
-    const bool extra = a.final_level && a.ex;
+    const bool extra = a.ex != nullptr;
     for (int t = tid; t < ns + (extra ? 1 : 0); t += MERGE_THREADS) {
         const int c = t < ns ? (int)a.in_cnt[(size_t)(s0 + t) * a.nq_pad + q] : (int)a.ex_cnt[q];
         sOff[t + 1] = min(c, a.k);
@@ -1339,9 +1340,9 @@ int index_reserve_rows(otter_index* ix, long long need_rows, hipStream_t st) {
 }
 
 // Merge the per-strip candidate lists of one scan, level by level (one workgroup sorts at most
-// MAX_SELECT composites).  final: write (D, I), optionally merging one more sorted list (ex);
-// otherwise leave ONE sorted list of <= k composites per query in list_out and the score key of
-// each query's k-th best in thr_out.
+// MAX_SELECT composites).  The last level also takes one more sorted list (ex), if given.  final: write
+// (D, I); otherwise leave ONE sorted list of <= k composites per query in list_out (which may be ex
+// itself) and the score key of each query's k-th best in thr_out.
 int run_merge(otter_index* ix, const u64* in, const u32* in_cnt, int cap_in, int S_in, long long nq, long long nq_pad,
               int k, bool final, float* D, long long* I, const u64* ex, const u32* ex_cnt, u64* list_out,
               u32* list_cnt, u32* thr_out, hipStream_t st) {
@@ -1364,8 +1365,8 @@ int run_merge(otter_index* ix, const u64* in, const u32* in_cnt, int cap_in, int
         ma.nq_pad = (int)nq_pad;
         ma.k = k;
         ma.final_level = (last && final) ? 1 : 0;
-        ma.ex = ma.final_level ? ex : nullptr;
-        ma.ex_cnt = ma.final_level ? ex_cnt : nullptr;
+        ma.ex = last ? ex : nullptr;
+        ma.ex_cnt = last ? ex_cnt : nullptr;
         ma.thr_out = nullptr;
         ma.npad = next_pow2(std::max(2, (std::min(S_in, fan) + (ma.ex ? 1 : 0)) * k));
         ma.npad = std::max(ma.npad, next_pow2(k));
@@ -1569,20 +1570,39 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
     const int total_tiles = (int)((ix->n + S16_BM - 1) / S16_BM);
     const int wgs = std::max(1, ix->ncu / qtiles);
     static const char* no_sample = getenv("OTTER_NO_SAMPLE");
-    // about 1/16 of the corpus (measured plateau: 1/16 .. 1/8; the sample pass itself runs at full occupancy and
-    // its own thresholds tighten as it goes), whole tiles per workgroup, at least 64 kk rows so that the seeded
-    // threshold is selective, at most 1/8 of the corpus
-    static const char* per_env = getenv("OTTER_SAMPLE_PER_WG");   // tuning runs only
-    int sample_tiles = std::max(total_tiles / 16, (int)((64ll * kk + S16_BM - 1) / S16_BM));
-    sample_tiles = (sample_tiles + wgs - 1) / wgs * wgs;
-    if (per_env) sample_tiles = std::max(1, atoi(per_env)) * wgs;
-    const bool sample = !no_sample && sample_tiles <= total_tiles / 8;
-    if (!sample) sample_tiles = 0;
+    // Sample levels.  A strip that starts without a threshold appends whole tiles and compacts after every
+    // second one (about 3x the time of a tile in steady state), so the first level is as small as the launch
+    // allows: `per0` tiles per workgroup, at least 4 kk rows in all.  Each further level scans three times what
+    // has been scanned so far with the threshold the levels before it produced (a tile then passes a few
+    // rows per query), until about 1/16 of the corpus is covered (measured plateau of the seeded main scan:
+    // 1/16 .. 1/8); no level may take the sample past 1/4 of the corpus.
+    static const char* per_env = getenv("OTTER_SAMPLE_PER_WG");     // tuning runs only: tiles per workgroup of level 0
+    static const char* lvl_env = getenv("OTTER_SAMPLE_LEVELS");     // ... most levels (1: a single level of 1/16)
+    static const char* frac_env = getenv("OTTER_SAMPLE_DIV");       // ... cover 1/DIV of the corpus (16)
+    const int max_levels = lvl_env ? std::max(1, atoi(lvl_env)) : 4;
+    const int cover = total_tiles / (frac_env ? std::max(4, atoi(frac_env)) : 16);
+    int lv_tiles[8], nlv = 0, sample_tiles = 0;
+    if (!no_sample) {
+        int l0 = std::max(1, (int)((4ll * kk + (long long)wgs * S16_BM - 1) / ((long long)wgs * S16_BM))) * wgs;
+        if (per_env) l0 = std::max(1, atoi(per_env)) * wgs;
+        if (max_levels == 1) l0 = std::max(l0, (std::max(cover, (int)((64ll * kk + S16_BM - 1) / S16_BM)) + wgs - 1) / wgs * wgs);
+        if (l0 <= total_tiles / 8) {
+            lv_tiles[nlv++] = l0;
+            sample_tiles = l0;
+            while (nlv < max_levels && nlv < 8 && sample_tiles < cover) {
+                int nx = (3 * sample_tiles + wgs - 1) / wgs * wgs;
+                if (nlv + 1 == max_levels) nx = std::max(nx, (cover - sample_tiles + wgs - 1) / wgs * wgs);
+                if (sample_tiles + nx > total_tiles / 4) break;
+                lv_tiles[nlv++] = nx;
+                sample_tiles += nx;
+            }
+        }
+    }
+    const bool sample = nlv > 0;
     const int main_tiles = total_tiles - sample_tiles;
     const int strips = std::min(wgs, main_tiles);
-    const int strips_s = sample ? std::min(wgs, sample_tiles) : 0;
-    if ((rc = ix->cand.reserve((size_t)std::max(strips, strips_s) * nq_pad * cfg.cap * sizeof(u64)))) return rc;
-    if ((rc = ix->cnt.reserve((size_t)std::max(strips, strips_s) * nq_pad * sizeof(u32)))) return rc;
+    if ((rc = ix->cand.reserve((size_t)wgs * nq_pad * cfg.cap * sizeof(u64)))) return rc;
+    if ((rc = ix->cnt.reserve((size_t)wgs * nq_pad * sizeof(u32)))) return rc;
     if (sample) {
         if ((rc = ix->smp.reserve((size_t)nq_pad * kk * sizeof(u64)))) return rc;
         if ((rc = ix->smpcnt.reserve((size_t)nq_pad * sizeof(u32)))) return rc;
@@ -1611,17 +1631,20 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
         }
         OTTER_HIP_TRY(hipEventRecord(ev.first, st));
     }
-    if (sample) {
-        sa.strips = strips_s;
-        sa.total_tiles = sample_tiles;
-        sa.tile_begin = 0;
-        sa.thr0 = nullptr;
-        cfg.launch(sa, qtiles * strips_s, st);
+    int done_tiles = 0;
+    for (int lv = 0; lv < nlv; ++lv) {
+        sa.strips = std::min(wgs, lv_tiles[lv]);
+        sa.total_tiles = lv_tiles[lv];
+        sa.tile_begin = done_tiles;
+        sa.thr0 = lv ? (const u32*)ix->thr0.p : nullptr;
+        cfg.launch(sa, qtiles * sa.strips, st);
         OTTER_HIP_TRY(hipGetLastError());
-        if ((rc = run_merge(ix, (const u64*)ix->cand.p, (const u32*)ix->cnt.p, cfg.cap, strips_s, nq, nq_pad, kk, false,
-                            nullptr, nullptr, nullptr, nullptr, (u64*)ix->smp.p, (u32*)ix->smpcnt.p, (u32*)ix->thr0.p,
-                            st)))
+        // the list of the levels so far is merged in place with this level's strips
+        if ((rc = run_merge(ix, (const u64*)ix->cand.p, (const u32*)ix->cnt.p, cfg.cap, sa.strips, nq, nq_pad, kk, false,
+                            nullptr, nullptr, lv ? (const u64*)ix->smp.p : nullptr, lv ? (const u32*)ix->smpcnt.p : nullptr,
+                            (u64*)ix->smp.p, (u32*)ix->smpcnt.p, (u32*)ix->thr0.p, st)))
             return rc;
+        done_tiles += lv_tiles[lv];
     }
     sa.strips = strips;
     sa.total_tiles = main_tiles;

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc csv output: per kernel, the mean of every counter over its dispatches."""
+"""Summarise rocprofv3 --pmc csv output: per kernel, the mean / min / max of every counter over its
+dispatches (min and max separate launches of one kernel that do different amounts of work)."""
 import csv
 import glob
 import os
@@ -21,7 +22,7 @@ def main(root):
         n = max(len(v) for v in ctrs.values())
         lines.append("%s  (dispatches=%d)" % (kern, n))
         for c, v in sorted(ctrs.items()):
-            lines.append("    %-28s mean %.6g" % (c, sum(v) / len(v)))
+            lines.append("    %-28s mean %.6g  min %.6g  max %.6g" % (c, sum(v) / len(v), min(v), max(v)))
     text = "\n".join(lines)
     print(text)
     with open(os.path.join(root, "summary.txt"), "w") as f:
