@@ -141,6 +141,16 @@ int64_t otter_index_last_refined(const otter_index* index);
 int otter_merge_topk(int device, const float* Dc, const int64_t* Ic, int G, int64_t nq, int k,
                      float* D, int64_t* I, void* stream);
 
+/* In-batch score matrix of the fine-tuning script's dev-set evaluation (reference
+ * scripts/train_1hop_tb_retrieval.py:304-319; the same matrix is the input of loss_single,
+ * retrieval/criterions.py:15-17): product[i][j] = q_i . c_j for j < B and, when neg_c is given,
+ * product[i][B] = q_i . neg_c_i (torch.mm + cat, float32).  rank[i] = how many columns sort before the
+ * target column i in descending order (equal scores: lower column first, as argmax picks), so
+ * accuracy = mean(rank == 0) and MRR = mean(1 / (rank + 1)).  All pointers are device pointers:
+ * q, c, neg_c float32 [B, d]; product float32 [B, B + (neg_c != NULL)]; rank int32 [B].  B <= 8192. */
+int otter_inbatch_scores(int device, const float* q, const float* c, const float* neg_c, int B, int d,
+                         float* product, int32_t* rank, void* stream);
+
 /* ---------------------------------------------------------------- encoder */
 
 typedef struct otter_encoder otter_encoder;

@@ -1176,6 +1176,55 @@ __global__ __launch_bounds__(NTHREADS) void pair_merge_kernel(PairMergeArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ in-batch score matrix
+// The dev-set evaluation of the fine-tuning script (reference scripts/train_1hop_tb_retrieval.py:304-319;
+// the same matrix feeds loss_single, retrieval/criterions.py:15-17): row i of `product` holds q_i . c_j for
+// every block j of the batch and, last, q_i . neg_c_i; the target of row i is column i.  rank[i] is the
+// number of columns that sort before the target in a descending order (an equal score in a lower column
+// sorts first: argmax's first-index rule), so accuracy = mean(rank == 0) and MRR = mean(1 / (rank + 1)).
+// One workgroup per row; one wave per score, lanes strided over d, fp32 fma partial sums and a butterfly.
+struct InbatchArgs {
+    const float* q;      // [B][d]
+    const float* c;      // [B][d]
+    const float* neg;    // [B][d] or null
+    float* product;      // [B][ncol]
+    int* rank;           // [B]
+    int B, d, ncol;
+};
+
+__global__ __launch_bounds__(256) void inbatch_kernel(InbatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* srow = reinterpret_cast<float*>(smem);         // [ncol]
+    int* scount = reinterpret_cast<int*>(srow + a.ncol);
+    const int i = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* qi = a.q + (size_t)i * a.d;
+    if (threadIdx.x == 0) *scount = 0;
+    for (int j = wave; j < a.ncol; j += 4) {
+        const float* cj = j < a.B ? a.c + (size_t)j * a.d : a.neg + (size_t)i * a.d;
+        float s = 0.0f;
+        for (int e = lane; e < a.d; e += 64) s = fmaf(qi[e], cj[e], s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) {
+            srow[j] = s;
+            a.product[(size_t)i * a.ncol + j] = s;
+        }
+    }
+    __syncthreads();
+    const float t = srow[i];
+    int before = 0;
+    for (int j = threadIdx.x; j < a.ncol; j += 256) {
+        const float v = srow[j];
+        before += (v > t) || (v == t && j < i);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+    if (lane == 0 && before) atomicAdd(scount, before);
+    __syncthreads();
+    if (threadIdx.x == 0) a.rank[i] = *scount;
+}
+
 // ------------------------------------------------------------------ host side
 
 constexpr long long QCHUNK = 16384;    // queries per scan launch (bounds scratch)
@@ -2249,6 +2298,28 @@ int otter_merge_topk(int device, const float* Dc, const int64_t* Ic, int G, int6
         attr_set[device] = true;
     }
     hipLaunchKernelGGL(pair_merge_kernel, dim3((unsigned)nq), dim3(NTHREADS), lds, (hipStream_t)stream, a);
+    OTTER_HIP_TRY(hipGetLastError());
+    return OTTER_OK;
+}
+
+int otter_inbatch_scores(int device, const float* q, const float* c, const float* neg_c, int B, int d, float* product,
+                         int32_t* rank, void* stream) {
+    if (B < 0 || d < 1) return set_err(OTTER_EINVAL, "inbatch_scores: bad B=%d d=%d", B, d);
+    if (B == 0) return OTTER_OK;
+    if (!q || !c || !product || !rank) return set_err(OTTER_EINVAL, "inbatch_scores: NULL buffer");
+    if (B > 8192) return set_err(OTTER_EINVAL, "inbatch_scores: B=%d exceeds 8192 (one row of scores is kept in LDS)", B);
+    DeviceGuard g(device);
+    if (!g.ok) return set_err(OTTER_EHIP, "inbatch_scores: hipSetDevice(%d) failed", device);
+    InbatchArgs a;
+    a.q = q;
+    a.c = c;
+    a.neg = neg_c;
+    a.product = product;
+    a.rank = rank;
+    a.B = B;
+    a.d = d;
+    a.ncol = B + (neg_c ? 1 : 0);
+    hipLaunchKernelGGL(inbatch_kernel, dim3((unsigned)B), dim3(256), (size_t)(a.ncol + 1) * sizeof(float), (hipStream_t)stream, a);
     OTTER_HIP_TRY(hipGetLastError());
     return OTTER_OK;
 }
