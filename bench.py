@@ -23,6 +23,7 @@ this box's host cores on a bounded row sample (rank 0, N = 1 only).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -190,6 +191,35 @@ def encode_leg(rank, world, local_rank, dist, steps, warmup, batch, cpu_ref):
     return res
 
 
+def scan16_dispatches(n, nq, k, d, nprod):
+    """Dispatches of scan16_kernel per search: the sample levels scan16_and_merge (otter_amd/csrc/index.hip) plans
+    for this shape, plus the main scan."""
+    margin = {3: max(28, k // 8), 2: max(44, math.ceil(k * max(0.6, 0.022 * math.sqrt(d)))),
+              1: max(60, math.ceil(k * max(1.0, 0.04 * math.sqrt(d))))}[nprod]
+    kk = k + margin
+    ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    qtiles, total = -(-nq // 256), -(-n // 256)
+    wgs = max(1, ncu // qtiles)
+    cover = total // (4 if qtiles >= 8 else 8)
+    l0 = max(1, -(-4 * kk // (wgs * 256))) * wgs
+    if l0 > total // 8:
+        return 1
+    more, c = 0, l0
+    while c < cover and more < 3:
+        more, c = more + 1, c * 4
+    ratio = (max(cover, l0) / l0) ** (1.0 / more) if more else 1.0
+    levels, done, target = 1, l0, float(l0)
+    for _ in range(more):
+        target *= ratio
+        nx = -(-(math.ceil(target) - done) // wgs) * wgs
+        if nx <= 0:
+            continue
+        if done + nx > total // 2:
+            break
+        levels, done = levels + 1, done + nx
+    return levels + 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -342,9 +372,10 @@ def main():
                      "go to the pass with one more product / the exact kernel). " % (
                          {1: 0, 2: 2, 3: 1}[nprod],
                          {1: "x_hi*q_hi", 2: "x_hi*q_hi + x_lo*q_hi", 3: "x_hi*q_hi + x_hi*q_lo + x_lo*q_hi"}[nprod]) +
-                     "kernel_ms is one HIP-event bracket per search on the launch stream = TWO dispatches of this kernel "
-                     "(threshold-seeding sample pass over the first tiles, then the main scan) and the ~0.12 ms merge "
-                     "between them: rocprof's TotalDurationNs of scan16_kernel / steps + that merge")
+                     "kernel_ms is one HIP-event bracket per search on the launch stream = %d dispatches of this kernel "
+                     "(threshold-seeding sample levels over the first 1/4 of the tiles, each started from the threshold "
+                     "of the levels before it, then the main scan) and the ~0.1 ms merges between them: rocprof's "
+                     "TotalDurationNs of scan16_kernel / steps + those merges" % scan16_dispatches(n, nq, k, d, nprod))
         else:
             kernel_flops, peak = flops, PEAK_FP32_MFMA_TFLOPS
             kname = "scan_kernel<4,2,2,2,32,3,8> (256x128 tile, fp32 v_mfma_f32_32x32x2_f32 + fused top-k filter)"
@@ -372,7 +403,7 @@ def main():
                          "traffic": args.traffic_bytes,
                          "kernel": kname,
                          "kernel_ms": kern_ms, "launches": int(launches),
-                         "kernel_dispatches_per_launch": 2 if split else 1,
+                         "kernel_dispatches_per_launch": scan16_dispatches(n, nq, k, d, nprod) if split else 1,
                          "kernel_flops_per_launch": kernel_flops,
                          "f32_equivalent_tflops": flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0,
                          "f32_equivalent_vs_f32_matrix_peak": (flops / (kern_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS)

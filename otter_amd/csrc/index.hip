@@ -507,7 +507,9 @@ __global__ __launch_bounds__(512, 2) void scan16_kernel(Scan16Args a) {
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         wg = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
     }
-    const int strip = wg / a.qtiles;           // an XCD's workgroups share corpus strips
+    // (the division runs on the vector ALU: readfirstlane brings the uniform results back to scalar registers,
+    // which the DMA bases derived from them must be in)
+    const int strip = __builtin_amdgcn_readfirstlane(wg / a.qtiles);           // an XCD's workgroups share corpus strips
     const int qt = wg - strip * a.qtiles;
     const int q0 = qt * S16_BQ;
     const int t0 = a.tile_begin + (int)(((long long)strip * a.total_tiles) / a.strips);
@@ -640,26 +642,44 @@ __global__ __launch_bounds__(512, 2) void scan16_kernel(Scan16Args a) {
     // threshold filter of one finished tile: lane = query (8 of them), 16 corpus rows per query
     auto epilogue = [&](int tile) {
         const long long rbase = (long long)tile * S16_BM + 64 * wn + 4 * fq;
+        const int lim = (int)std::min<long long>(a.n - rbase, 1 << 20);     // this lane's rows rbase + j are real for j < lim
+        // The lane's first query, made opaque here: every address below is derived from it INSIDE the epilogue.
+        // Left to itself the compiler computes the eight LDS addresses and eight 64-bit row pointers once,
+        // before the main loop, spills them, and reloads them at every use behind a wait that also drains the
+        // tile loads in flight.
+        int qb = 128 * g + fr;
+        asm volatile("" : "+v"(qb));
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
-            const int ql = 128 * g + 16 * m + fr;
+            const int ql = qb + 16 * m;
             const u32 thr = sThr[ql];
             const float thrf = key2f(thr);
-            u64* qbuf = candBase + (size_t)ql * CAP;
+            const u32 qslot = (u32)ql * (u32)CAP;      // 32-bit slot index against the uniform base
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 const f32x4 v = acc[m][nb];
                 const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
                 if (thr == 0u || mx > thrf || mx != mx) {
+                    // the lane's survivors among its 4 scores take their slots with ONE LDS atomic
+                    u32 key[4];
+                    bool hit[4];
+                    u32 c = 0;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const long long grow = rbase + 16 * nb + i;
-                        const u32 key = f2key(v[i]);
-                        if (key > thr && grow < a.n) {
-                            const u32 pos = atomicAdd(&sCnt[ql], 1u);
-                            if (pos < (u32)CAP) qbuf[pos] = ((u64)key << 32) | (u64)(0xFFFFFFFFu - (u32)grow);
-                            if (pos + 1 > (u32)(CAP - S16_BM)) *sFlag = 1;
-                        }
+                        key[i] = f2key(v[i]);
+                        hit[i] = key[i] > thr && 16 * nb + i < lim;
+                        c += hit[i] ? 1u : 0u;
+                    }
+                    if (c) {
+                        u32 pos = atomicAdd(&sCnt[ql], c);
+                        const u32 low0 = 0xFFFFFFFFu - (u32)(rbase + 16 * nb);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (hit[i]) {
+                                if (pos < (u32)CAP) candBase[qslot + pos] = ((u64)key[i] << 32) | (u64)(low0 - (u32)i);
+                                ++pos;
+                            }
+                        if (pos > (u32)(CAP - S16_BM)) *sFlag = 1;
                     }
                 }
             }
@@ -1623,13 +1643,13 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
     // second one (about 3x the time of a tile in steady state), so the first level is as small as the launch
     // allows: `per0` tiles per workgroup, at least 4 kk rows in all.  Each further level scans three times what
     // has been scanned so far with the threshold the levels before it produced (a tile then passes a few
-    // rows per query), until about 1/16 of the corpus is covered (measured plateau of the seeded main scan:
-    // 1/16 .. 1/8); no level may take the sample past 1/4 of the corpus.
+    // rows per query), in geometric steps that end at 1/DIV of the corpus.
     static const char* per_env = getenv("OTTER_SAMPLE_PER_WG");     // tuning runs only: tiles per workgroup of level 0
     static const char* lvl_env = getenv("OTTER_SAMPLE_LEVELS");     // ... most levels (1: a single level of 1/16)
-    static const char* frac_env = getenv("OTTER_SAMPLE_DIV");       // ... cover 1/DIV of the corpus (16)
+    static const char* frac_env = getenv("OTTER_SAMPLE_DIV");       // ... cover 1/DIV of the corpus
     const int max_levels = lvl_env ? std::max(1, atoi(lvl_env)) : 4;
-    const int cover = total_tiles / (frac_env ? std::max(4, atoi(frac_env)) : 16);
+    // measured (1M x 768): 1/4 is best from 8 query tiles on (few, long strips), 1/8 .. 1/16 below
+    const int cover = total_tiles / (frac_env ? std::max(2, atoi(frac_env)) : (qtiles >= 8 ? 4 : 8));
     int lv_tiles[8], nlv = 0, sample_tiles = 0;
     if (!no_sample) {
         int l0 = std::max(1, (int)((4ll * kk + (long long)wgs * S16_BM - 1) / ((long long)wgs * S16_BM))) * wgs;
@@ -1638,10 +1658,16 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
         if (l0 <= total_tiles / 8) {
             lv_tiles[nlv++] = l0;
             sample_tiles = l0;
-            while (nlv < max_levels && nlv < 8 && sample_tiles < cover) {
-                int nx = (3 * sample_tiles + wgs - 1) / wgs * wgs;
-                if (nlv + 1 == max_levels) nx = std::max(nx, (cover - sample_tiles + wgs - 1) / wgs * wgs);
-                if (sample_tiles + nx > total_tiles / 4) break;
+            // geometric growth of the rows scanned so far, about 4x per level, ending at `cover`
+            int more = 0;
+            for (long long c = l0; c < cover && more < max_levels - 1 && more < 7; c *= 4) ++more;
+            const double ratio = more ? std::pow((double)std::max(cover, l0) / l0, 1.0 / more) : 1.0;
+            double target = l0;
+            for (int i = 0; i < more; ++i) {
+                target *= ratio;
+                const int nx = ((int)std::ceil(target) - sample_tiles + wgs - 1) / wgs * wgs;
+                if (nx <= 0) continue;
+                if (sample_tiles + nx > total_tiles / 2) break;
                 lv_tiles[nlv++] = nx;
                 sample_tiles += nx;
             }
@@ -1695,6 +1721,7 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
             return rc;
         done_tiles += lv_tiles[lv];
     }
+    if (getenv("OTTER_DIAG_NOHIT") && sample) (void)hipMemsetAsync(ix->thr0.p, 0xFF, (size_t)nq_pad * 4, st);  // DIAG ONLY
     sa.strips = strips;
     sa.total_tiles = main_tiles;
     sa.tile_begin = sample_tiles;
