@@ -205,7 +205,7 @@ def scan16_dispatches(n, nq, k, d, nprod):
     if l0 > total // 8:
         return 1
     more, c = 0, l0
-    while c < cover and more < 3:
+    while c < cover and more < (3 if qtiles >= 8 else 2) - 1:
         more, c = more + 1, c * 4
     ratio = (max(cover, l0) / l0) ** (1.0 / more) if more else 1.0
     levels, done, target = 1, l0, float(l0)

@@ -919,14 +919,37 @@ __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        for (int j = 0; j < a.ld / 8; ++j) {
-            const float4 af = *reinterpret_cast<const float4*>(xrow + 8 * j + 4 * h);
-            const float4 bf = *reinterpret_cast<const float4*>(qrow + 8 * j + 4 * h);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
+        // a gather of 32 scattered rows: the loads of the next four k-groups are in flight while the current
+        // four are multiplied (same MFMA sequence as the plain loop: the sums are unchanged)
+        constexpr int U = 4;
+        const int nj = a.ld / 8, njU = nj / U * U;
+        float4 af[2][U], bf[2][U];
+        auto fetch = [&](int buf, int j0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                af[buf][u] = *reinterpret_cast<const float4*>(xrow + 8 * (j0 + u) + 4 * h);
+                bf[buf][u] = *reinterpret_cast<const float4*>(qrow + 8 * (j0 + u) + 4 * h);
+            }
+        };
+        auto mul = [&](const float4& x, const float4& q) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, q.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, q.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, q.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, q.w, acc, 0, 0, 0);
+        };
+        if (njU) fetch(0, 0);
+        for (int j0 = 0; j0 < njU; j0 += 2 * U) {
+            if (j0 + U < njU) fetch(1, j0 + U);
+#pragma unroll
+            for (int u = 0; u < U; ++u) mul(af[0][u], bf[0][u]);
+            if (j0 + U < njU) {
+                if (j0 + 2 * U < njU) fetch(0, j0 + 2 * U);
+#pragma unroll
+                for (int u = 0; u < U; ++u) mul(af[1][u], bf[1][u]);
+            }
         }
+        for (int j = njU; j < nj; ++j)
+            mul(*reinterpret_cast<const float4*>(xrow + 8 * j + 4 * h), *reinterpret_cast<const float4*>(qrow + 8 * j + 4 * h));
         // lane (column l31, half h) holds rows (r & 3) + 8 (r >> 2) + 4 h; all columns are equal:
         // column 0's two lanes publish the 32 scores
 #pragma unroll
@@ -1647,8 +1670,9 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
     static const char* per_env = getenv("OTTER_SAMPLE_PER_WG");     // tuning runs only: tiles per workgroup of level 0
     static const char* lvl_env = getenv("OTTER_SAMPLE_LEVELS");     // ... most levels (1: a single level of 1/16)
     static const char* frac_env = getenv("OTTER_SAMPLE_DIV");       // ... cover 1/DIV of the corpus
-    const int max_levels = lvl_env ? std::max(1, atoi(lvl_env)) : 4;
-    // measured (1M x 768): 1/4 is best from 8 query tiles on (few, long strips), 1/8 .. 1/16 below
+    // measured (1M x 768; a level costs a launch and a merge, a looser threshold costs appends): three levels
+    // ending at 1/4 from 8 query tiles on (few, long strips), two levels ending at 1/8 below
+    const int max_levels = lvl_env ? std::max(1, atoi(lvl_env)) : (qtiles >= 8 ? 3 : 2);
     const int cover = total_tiles / (frac_env ? std::max(2, atoi(frac_env)) : (qtiles >= 8 ? 4 : 8));
     int lv_tiles[8], nlv = 0, sample_tiles = 0;
     if (!no_sample) {
