@@ -363,7 +363,7 @@ def main():
         value = world * nq * args.steps / elapsed
         kern_ms = scan_ms / max(launches, 1)
         flops = 2.0 * n * d * nq
-        split = nq >= 65 and n >= 65536 and not os.environ.get("OTTER_NO_SPLIT")
+        split = nq >= 33 and n >= 65536 and not os.environ.get("OTTER_NO_SPLIT")
         nprod = {"1": 3, "2": 2}.get(os.environ.get("OTTER_SPLIT_MODE", ""), 1)
         if split:   # coarse pass on bf16 planes of the fp32 operands: 1 (default), 2 or 3 MFMA products per term
             kernel_flops, peak = float(nprod) * flops, PEAK_BF16_MFMA_TFLOPS

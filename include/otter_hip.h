@@ -129,7 +129,7 @@ int otter_index_timing(otter_index* ix, double* scan_ms, int64_t* scan_launches)
  * queries of the last search() took that second route (0 in the usual case). */
 int64_t otter_index_last_fallback(const otter_index* ix);
 /* Queries of the last search() that the two-product coarse pass could not prove and that were searched again
- * with the three-product pass (or, if fewer than 65, by the exact kernel); 0 on the other paths. */
+ * with the three-product pass (or, if fewer than 33, by the exact kernel); 0 on the other paths. */
 int64_t otter_index_last_refined(const otter_index* index);
 
 /* Final merge of the row-sharded search: G sorted candidate lists per query

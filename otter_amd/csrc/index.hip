@@ -1508,7 +1508,8 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
         // MFMA-bound batches on a large corpus: coarse pass on the bf16 matrix cores + exact re-scoring
         static const char* no_split_env = getenv("OTTER_NO_SPLIT");
         static const char* split_min_env = getenv("OTTER_SPLIT_MIN_NQ");   // tuning runs only
-        static const int split_min = split_min_env ? atoi(split_min_env) : 65;   // above the 64-query tile of the exact kernel
+        static const int split_min = split_min_env ? atoi(split_min_env) : 33;   // above the 32-query tile of the exact kernel, the
+                                                                                 // last one that is HBM-bound (measured: 33..64 queries 1.0 -> 0.7 ms)
         static const char* mode_env = getenv("OTTER_SPLIT_MODE");          // "1": three-product coarse pass first
         if (!no_split_env && !ix->no_split && nq >= split_min && ix->n >= 65536 && split_kc(k, 1, ix->d) <= S16_MAX_K) {
             const int rs = ensure_split_planes(ix, st);
@@ -1961,7 +1962,7 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
     for (size_t i = 0; i < which.size(); ++i)
         OTTER_HIP_TRY(hipMemcpyAsync((float*)bq.p + i * ix->d, qd + (size_t)which[i] * ix->d,
                                      (size_t)ix->d * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (mode >= 2 && nf >= 65) {
+    if (mode >= 2 && nf >= 33) {
         const int next = (mode == 3 && !ix->two_prod_off && split_kc(k, 2, ix->d) <= S16_MAX_K) ? 2 : 1;
         rc = search_chunk_split(ix, (const float*)bq.p, nf, k, (float*)bD.p, (long long*)bI.p, st, next, false);
     } else {
