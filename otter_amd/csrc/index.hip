@@ -482,6 +482,7 @@ struct Scan16Args {
     int qtiles, strips, total_tiles;
     int tile_begin;     // first tile of this launch (tiles below belong to the sample pass)
     const u32* thr0;    // [nq_pad] initial score-key threshold per query (null: none)
+    int skip_final;     // 1: leave the strip's candidates as they are (<= CAP per query); the merge selects
 };
 
 constexpr int S16_HT = 16384, S16_BUF = 4 * S16_HT;
@@ -779,7 +780,14 @@ __global__ __launch_bounds__(512, 2) void scan16_kernel(Scan16Args a) {
         }
         // after the last tile group 1 did not fall behind again: the groups are level here
     }
-    compact_pass(true);
+    // (a one-tile strip of the first sample level has nothing to gain from a compaction of 32 queries per
+    // wave, one after the other: the merge kernel takes all its <= 256 rows per query)
+    if (a.skip_final) {
+        wait_vmcnt<0>();
+        wg_barrier();
+    } else {
+        compact_pass(true);
+    }
     for (int i = tid; i < S16_BQ; i += 512) a.cnt[(size_t)strip * a.nq_pad + q0 + i] = sCnt[i];
 }
 
@@ -1028,6 +1036,7 @@ struct MergeArgs {
     int k;
     int npad;            // power of two >= fan * min(cap_in, k) (+ k with an extra list)
     int final_level;
+    int take;            // entries gathered from each strip list (k; more only for uncompacted one-tile strips)
     const u64* ex;       // last level only: one more sorted list [nq_pad][k] (the sample passes so far), or null;
                          // may alias `out` (a workgroup has gathered its query's lists before it writes)
     const u32* ex_cnt;   // [nq_pad]
@@ -1069,7 +1078,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(MergeArgs a) {
     const bool extra = a.ex != nullptr;
     for (int t = tid; t < ns + (extra ? 1 : 0); t += MERGE_THREADS) {
         const int c = t < ns ? (int)a.in_cnt[(size_t)(s0 + t) * a.nq_pad + q] : (int)a.ex_cnt[q];
-        sOff[t + 1] = min(c, a.k);
+        sOff[t + 1] = min(c, t < ns ? a.take : a.k);
     }
     __syncthreads();
     if (wave == 0) {   // inclusive scan of <= MERGE_MAX_STRIPS + 1 counts by one wave
@@ -1437,8 +1446,9 @@ int index_reserve_rows(otter_index* ix, long long need_rows, hipStream_t st) {
 // itself) and the score key of each query's k-th best in thr_out.
 int run_merge(otter_index* ix, const u64* in, const u32* in_cnt, int cap_in, int S_in, long long nq, long long nq_pad,
               int k, bool final, float* D, long long* I, const u64* ex, const u32* ex_cnt, u64* list_out,
-              u32* list_cnt, u32* thr_out, hipStream_t st) {
-    const int fan = std::min(MERGE_MAX_STRIPS, std::max(2, MAX_SELECT / k - (ex ? 1 : 0)));
+              u32* list_cnt, u32* thr_out, hipStream_t st, int take_first = 0) {
+    int take = take_first > 0 ? take_first : k;      // first level only; later levels read lists of <= k
+    int fan = std::min(MERGE_MAX_STRIPS, std::max(2, (MAX_SELECT - (ex ? k : 0)) / take));
     int pp = 0, rc;
     for (;;) {
         const int S_out = (S_in + fan - 1) / fan;
@@ -1454,13 +1464,14 @@ int run_merge(otter_index* ix, const u64* in, const u32* in_cnt, int cap_in, int
         ma.cap_in = cap_in;
         ma.S_in = S_in;
         ma.fan = fan;
+        ma.take = take;
         ma.nq_pad = (int)nq_pad;
         ma.k = k;
         ma.final_level = (last && final) ? 1 : 0;
         ma.ex = last ? ex : nullptr;
         ma.ex_cnt = last ? ex_cnt : nullptr;
         ma.thr_out = nullptr;
-        ma.npad = next_pow2(std::max(2, (std::min(S_in, fan) + (ma.ex ? 1 : 0)) * k));
+        ma.npad = next_pow2(std::max(2, std::min(S_in, fan) * take + (ma.ex ? k : 0)));
         ma.npad = std::max(ma.npad, next_pow2(k));
         if (!ma.final_level) {
             if (last) {
@@ -1488,6 +1499,8 @@ int run_merge(otter_index* ix, const u64* in, const u32* in_cnt, int cap_in, int
         in = ma.out;
         in_cnt = ma.out_cnt;
         cap_in = k;
+        take = k;
+        fan = std::min(MERGE_MAX_STRIPS, std::max(2, MAX_SELECT / k - (ex ? 1 : 0)));
         S_in = S_out;
         pp ^= 1;
     }
@@ -1737,16 +1750,20 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
         sa.total_tiles = lv_tiles[lv];
         sa.tile_begin = done_tiles;
         sa.thr0 = lv ? (const u32*)ix->thr0.p : nullptr;
+        // one-tile strips of level 0 that one merge workgroup can take whole: no compaction in the scan
+        const bool whole = lv == 0 && lv_tiles[0] == sa.strips && sa.strips * S16_BM <= MAX_SELECT && S16_BM <= cfg.cap;
+        sa.skip_final = whole ? 1 : 0;
         cfg.launch(sa, qtiles * sa.strips, st);
         OTTER_HIP_TRY(hipGetLastError());
         // the list of the levels so far is merged in place with this level's strips
         if ((rc = run_merge(ix, (const u64*)ix->cand.p, (const u32*)ix->cnt.p, cfg.cap, sa.strips, nq, nq_pad, kk, false,
                             nullptr, nullptr, lv ? (const u64*)ix->smp.p : nullptr, lv ? (const u32*)ix->smpcnt.p : nullptr,
-                            (u64*)ix->smp.p, (u32*)ix->smpcnt.p, (u32*)ix->thr0.p, st)))
+                            (u64*)ix->smp.p, (u32*)ix->smpcnt.p, (u32*)ix->thr0.p, st, whole ? S16_BM : 0)))
             return rc;
         done_tiles += lv_tiles[lv];
     }
     if (getenv("OTTER_DIAG_NOHIT") && sample) (void)hipMemsetAsync(ix->thr0.p, 0xFF, (size_t)nq_pad * 4, st);  // DIAG ONLY
+    sa.skip_final = 0;
     sa.strips = strips;
     sa.total_tiles = main_tiles;
     sa.tile_begin = sample_tiles;
