@@ -5,26 +5,39 @@
 
 Workload (BASELINE.json configs[1]): exact top-100 inner-product search of a 2,214-query
 batch (OTT-QA dev size) over a 1,000,000 x 768 fp32 corpus resident in HBM, per GPU.
-A "step" is one search of the whole query batch.  At N > 1 (one process per GPU, launched
-by torch.distributed.run) every rank holds its own 1M-row shard of an N*1M-row corpus
-(row-sharded, weak scaling), searches it for the same queries, and the per-shard top-k
-lists are exchanged with one RCCL all-gather and merged on the GPU; `value` counts the
-1M-row query scans all ranks complete per second (N * 2214 per step), which at N = 1 is
-plain queries/s on configs[1].
+A "step" is one search of the whole query batch.
 
-One JSON line on stdout (rank 0).  `roofline` is for the scan kernel (fp32 MFMA bound at
-nq = 2214).  Large batches run the coarse pass of the exact search on the bf16 matrix cores
-(every fp32 operand split into bf16 hi + lo, three MFMA products per term), so the kernel's work
-per launch is 3 * 2*N*d*nq bf16 flops against the dense bf16 MFMA peak; the fp32-equivalent rate
-2*N*d*nq / t is printed beside it.  Time = HIP events around the kernel, taken inside the timed
-region by the library's timing hook on the launch stream.
-`cpu_baseline` is oracle/flat_ip.py (numpy sgemm + k-select port of IndexFlatIP) timed on
-this box's host cores on a bounded row sample (rank 0, N = 1 only).
+N > 1: one process per GPU.  `python bench.py --gpus N` starts the N ranks itself (a child
+`python -m torch.distributed.run --nproc-per-node N bench.py ...`, started before this process
+touches the GPU; the reference's multi-GPU modes are single-command too,
+scripts/eval_ottqa_retrieval.py:110-112, scripts/encode_corpus.py:109-113); launched under
+torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.  Every rank
+holds its own 1M-row shard of an N x 1M-row corpus (row-sharded, weak scaling) inside
+otter_amd.sharded.ShardedIndexFlatIP -- the class the gloo tests cover -- which searches the
+shard for all queries, exchanges the packed (id, score) candidates with ONE RCCL all-gather and
+merges them on the GPU.  `value` counts the 1M-row query scans all ranks complete per second
+(N * 2214 per step), which at N = 1 is plain queries/s on configs[1].  The run fails if the
+process group that forms is not N ranks.
+
+One JSON line on stdout (rank 0).  `roofline` is for the scan kernel of the timed step: large
+batches run the coarse pass of the exact search on the bf16 matrix cores (bf16 planes of the fp32
+operands), so the kernel's work per launch is nprod * 2*N*d*nq bf16 flops against the dense bf16
+MFMA peak; the fp32-equivalent rate 2*N*d*nq / t is printed beside it.  Time = HIP events around
+the kernel, taken inside the timed region by the library's timing hook on the launch stream.
+Untimed-by-`value` legs on rank 0 at N = 1: `small_batches` (nq = 1 / 8 / 32, the reference's
+real call pattern and the HBM-bound regime: scan ms, wall ms, GB/s against 8 TB/s), `pcie`
+(host numpy in / out of the same search), `dim2304` (the dimension the reference script uses,
+scripts/eval_ottqa_retrieval.py:74), `encode` (corpus-encode blocks/s, BASELINE.json configs[3]).
+`cpu_baseline` is oracle/flat_ip.py (numpy sgemm + k-select port of IndexFlatIP, one batched call)
+timed on this box's host cores on a bounded row sample, with the reference-style form beside it
+(one scan + heap select per query, the shape of the reference's nq = 1 calls from 24 processes).
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -50,14 +63,19 @@ def gen_rows(n, d, seed, device, chunk=131072):
     return out
 
 
-def cpu_baseline(xb_sample_fn, q, k, rows_full, budget_s=15.0):
-    """Time the numpy port on a bounded sample of the same workload."""
-    from oracle import flat_ip
+def host_cores():
     try:
         from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        return int(max([p.get("num_threads", 1) for p in threadpool_info()] or [1]))
     except Exception:
-        cores = os.cpu_count() or 1
+        return int(os.cpu_count() or 1)
+
+
+def cpu_baseline(xb_sample_fn, q, k, rows_full, budget_s=12.0):
+    """Time the CPU port on bounded samples of the same workload (rank 0, N = 1 only).
+    (ii) of SURVEY.md §8d: one batched call; (i): the reference's way, one scan per query."""
+    from oracle import flat_ip
+    cores = host_cores()
     nq = q.shape[0]
     # calibration pass, then one pass sized to the budget
     rows = 20000
@@ -74,23 +92,38 @@ def cpu_baseline(xb_sample_fn, q, k, rows_full, budget_s=15.0):
         dt = time.perf_counter() - t0
         rows = rows2
     scans_per_s = nq / dt * (rows / rows_full)
-    return {"value": scans_per_s, "unit": "queries/s", "cores": int(cores), "kind": "port",
-            "sample": "%d queries x first %d of %d rows, numpy sgemm + k-select (oracle/flat_ip.py), "
-                      "%.1f s, scaled by rows" % (nq, rows, rows_full, dt)}
+    out = {"value": scans_per_s, "unit": "queries/s", "cores": cores, "kind": "port",
+           "sample": "%d queries x first %d of %d rows, one batched call: numpy sgemm + k-select "
+                     "(oracle/flat_ip.py), %.1f s, scaled by rows" % (nq, rows, rows_full, dt)}
+    # the reference's call pattern (scripts/eval_ottqa_retrieval.py:126-129,156): nq = 1 per call from a
+    # pool of processes = one sequential scan + heap select per query, queries spread over the cores
+    nthreads = flat_ip.num_threads()
+    nq1 = min(nq, 4 * nthreads)
+    rows1 = min(rows_full, 100000)
+    xb1 = xb_sample_fn(rows1)
+    t0 = time.perf_counter()
+    flat_ip.search_c(xb1, q[:nq1], k, mode=flat_ip.MODE_SIMD8)
+    dt1 = time.perf_counter() - t0
+    out["per_query_calls"] = {
+        "value": nq1 / dt1 * (rows1 / rows_full), "unit": "queries/s", "cores": nthreads, "kind": "port",
+        "sample": "%d queries x first %d of %d rows, one scan + heap k-select per query (oracle/flat_ip.c, "
+                  "8-lane SIMD-shaped dot product), %.1f s, scaled by rows" % (nq1, rows1, rows_full, dt1)}
+    return out
 
 
-
-
-def encode_leg(rank, world, local_rank, dist, steps, warmup, batch, cpu_ref):
+def encode_leg(rank, world, local_rank, dist, steps, warmup, batch, cpu_ref, rehearse):
     """Second half of the metric: corpus-encode blocks/s (BASELINE.json configs[3] shape: roberta-base,
     512-token blocks, bf16, data-parallel = every rank encodes its own blocks with resident weights,
-    no data-path collective).  Synthetic ids per SURVEY.md §8d, random weights (seed 99)."""
+    no data-path collective).  Synthetic ids per SURVEY.md §8d, random weights (seed 99).  The timed loop
+    feeds DISTINCT host batches through the encode driver's pipelined predict(): pinned token upload on a
+    copy stream, forward, asynchronous download of the embeddings -- blocks/s includes both PCIe legs."""
     from types import SimpleNamespace
-    from oracle import encoder_ref as R     # shape + seeded weight generator; CPU baseline below
     from otter_amd import encoder as E
+    from otter_amd import synthetic as S
+    from otter_amd.encode_driver import predict
     L, H, layers = 512, 768, 12
-    cfg = R.make_config("roberta")
-    sd = R.make_state_dict(cfg, 99)
+    cfg = S.make_config("roberta")
+    sd = S.make_state_dict(cfg, 99)
     hf = SimpleNamespace(**{k: cfg[k] for k in ("vocab_size", "hidden_size", "num_hidden_layers",
                                                 "num_attention_heads", "intermediate_size",
                                                 "max_position_embeddings", "type_vocab_size", "pad_token_id",
@@ -99,37 +132,48 @@ def encode_leg(rank, world, local_rank, dist, steps, warmup, batch, cpu_ref):
     model = E.RobertaSingleEncoderThreeCatPool(hf, a, dtype="bf16")
     model.load_state_dict(sd, strict=False)
     model.to("cuda:%d" % local_rank)
-    rs = np.random.RandomState(777 + rank)
-    ids = rs.randint(3, cfg["vocab_size"], size=(batch, L)).astype(np.int64)
-    ids[:, 0] = 0
-    ids[:, 128] = 2
-    ids[:, 129] = 2
-    ids[:, L - 1] = 2
-    p2 = np.zeros((batch, L), np.int64)
-    p2[:, 1:128] = 1
-    p3 = np.zeros((batch, L), np.int64)
-    p3[:, 130:L - 1] = 1
-    b = {"input_ids": torch.from_numpy(ids).cuda(), "input_mask": torch.ones((batch, L), dtype=torch.int64).cuda(),
-         "part2_mask": torch.from_numpy(p2).cuda(), "part3_mask": torch.from_numpy(p3).cuda()}
+
+    def host_batch(seed):
+        rs = np.random.RandomState(seed)
+        ids = rs.randint(3, cfg["vocab_size"], size=(batch, L)).astype(np.int64)
+        ids[:, 0] = 0
+        ids[:, 128] = 2
+        ids[:, 129] = 2
+        ids[:, L - 1] = 2
+        p2 = np.zeros((batch, L), np.int64)
+        p2[:, 1:128] = 1
+        p3 = np.zeros((batch, L), np.int64)
+        p3[:, 130:L - 1] = 1
+        return {"input_ids": torch.from_numpy(ids), "input_mask": torch.ones((batch, L), dtype=torch.int64),
+                "part2_mask": torch.from_numpy(p2), "part3_mask": torch.from_numpy(p3)}
+
+    nb_distinct = 4
+    hbs = [host_batch(777 + 1000 * rank + i) for i in range(nb_distinct)]
+    b = {k: v.cuda() for k, v in hbs[0].items()}
     for _ in range(warmup):
         out = model(b)["embed"]
+    predict(model, hbs[:2])        # pipeline warm-up (pinned staging buffers, copy stream)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    emb = predict(model, (hbs[i % nb_distinct] for i in range(steps)))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    assert emb.shape == (steps * batch, 3 * H)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else b["input_ids"].device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # device time of the forward alone (resident batch), for the roofline figure
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(steps):
         out = model(b)["embed"]
     e1.record()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if os.environ.get("OTTER_BENCH_REHEARSE") == "1" else out.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     if rank != 0:
         return None
     dev_ms = e0.elapsed_time(e1) / steps
@@ -137,7 +181,9 @@ def encode_leg(rank, world, local_rank, dist, steps, warmup, batch, cpu_ref):
     achieved = flops_block * batch / (dev_ms * 1e-3) / 1e12
     res = {"value": world * batch * steps / elapsed, "unit": "blocks/s", "dtype": "bf16", "batch_per_gpu": batch,
            "seq_len": L, "model": "roberta-base shape, random init", "ms_per_batch": elapsed / steps * 1e3,
-           "finite": bool(torch.isfinite(out).all().item()),
+           "includes": "pinned H2D of 4 x int64 [B, 512] per batch on a copy stream + D2H of the float32 [B, 2304] "
+                       "embeddings (otter_amd.encode_driver.predict), %d distinct host batches" % nb_distinct,
+           "finite": bool(torch.isfinite(emb).all().item()),
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
                         "kernel": "whole forward (12 x [qkv gemm, attention, o gemm, ffn1 gemm, ffn2 gemm], LayerNorms folded into the gemm epilogues)",
@@ -172,12 +218,16 @@ def encode_leg(rank, world, local_rank, dist, steps, warmup, batch, cpu_ref):
     res["ragged_variant"] = {"value": batch / rdt, "unit": "blocks/s (this rank)", "mean_tokens": float(m2.sum()) / batch,
                              "padded_to": L, "ms_per_batch": rdt * 1e3,
                              "finite": bool(torch.isfinite(rout).all().item()),
-                             "note": "lengths ~U[64,512]; rows past the last masked-in position are not computed"}
+                             "note": "lengths ~U[64,512]; rows past the last masked-in position are not computed; "
+                                     "resident batch (no PCIe legs)"}
     if cpu_ref:
-        # fp32 recall-style check of the bf16 path on 2 blocks + CPU baseline timing (oracle restatement)
+        # cosine of the bf16 path against the fp32 CPU restatement + CPU baseline timing (oracle).  The sample
+        # is bounded by this file's budget (10-30 s of CPU work: ~9 blocks/s on 16 threads), not the >= 512
+        # blocks SURVEY.md §8d suggests, which would take a minute by themselves.
+        from oracle import encoder_ref as R
         ref = R.EncoderRef(cfg, sd)
-        nb = 96                                      # ~10 s of CPU work at ~9 blocks/s
-        small = {k: v[:nb].cpu() for k, v in b.items()}
+        nb = min(batch, 128)
+        small = {k: v[:nb] for k, v in hbs[0].items()}
         ref({k: v[:4] for k, v in small.items()})    # warm-up (thread pool, allocations)
         t0 = time.perf_counter()
         exp = torch.cat([ref({k: v[i:i + 8] for k, v in small.items()})["embed"] for i in range(0, nb, 8)], 0)
@@ -220,6 +270,65 @@ def scan16_dispatches(n, nq, k, d, nprod):
     return levels + 1
 
 
+def timed_search(index, q, k, steps, warmup):
+    """(scan ms per search from the library's HIP-event hook, wall ms per search) of index.search(q, k)."""
+    for _ in range(warmup):
+        index.search(q, k)
+    index.set_timing(True)
+    index.timing()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        index.search(q, k)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    ms, launches = index.timing()
+    index.set_timing(False)
+    return ms / max(launches, 1), wall
+
+
+def small_batch_leg(index, q, k, n, d):
+    """The reference's real call pattern (nq = 1 per call, scripts/eval_ottqa_retrieval.py:126-129) and the
+    rest of the HBM-bound regime: one corpus read per search, N*d*4 algorithmic bytes."""
+    out = []
+    for nq in (1, 8, 32):
+        scan_ms, wall_ms = timed_search(index, q[:nq].contiguous(), k, 30, 5)
+        byts = float(n) * d * 4
+        out.append({"nq": nq, "scan_ms": scan_ms, "wall_ms": wall_ms, "queries_per_s": nq / (wall_ms * 1e-3),
+                    "GBps_scan": byts / (scan_ms * 1e-3) / 1e9, "GBps_wall": byts / (wall_ms * 1e-3) / 1e9,
+                    "hbm_frac_scan": byts / (scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                    "hbm_frac_wall": byts / (wall_ms * 1e-3) / 1e9 / PEAK_HBM_GBS})
+    return {"bound": "hbm", "peak_GBps": PEAK_HBM_GBS, "algorithmic_bytes_per_search": float(n) * d * 4,
+            "note": "scan_ms = HIP events around every kernel that reads corpus rows; wall_ms = host clock per "
+                    "search() call incl. every side kernel", "points": out}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as children of a
+    torch.distributed.run child process and pass its exit code on.  This process has not touched the GPU
+    (no HIP call yet; torch.cuda.device_count() does not initialise it on this image)."""
+    rehearse = os.environ.get("OTTER_BENCH_REHEARSE") == "1"
+    if not rehearse:
+        have = torch.cuda.device_count()
+        if have < n:
+            print("bench.py: --gpus %d but only %d GPU(s) visible (OTTER_BENCH_REHEARSE=1 runs every rank on GPU 0 "
+                  "with a gloo exchange)" % (n, have), file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -231,22 +340,29 @@ def main():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode", action="store_true", help="skip the corpus-encode leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the small-batch / PCIe / d=2304 legs")
     ap.add_argument("--encode-batch", type=int, default=128)
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per scan launch from a separate rocprofv3 --pmc pass (profiles/)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     if (args.traffic_bytes is None and (args.rows, args.dim, args.nq, args.k) == (1000000, 768, 2214, 100)
             and not os.environ.get("OTTER_NO_SPLIT")):
-        # HBM-side bytes per scan launch from this round's separate rocprofv3 --pmc passes (profiles/)
-        tp = os.path.join(ROOT, "profiles", "r01_traffic_split.json")
-        if os.path.exists(tp):
-            with open(tp) as f:
-                args.traffic_bytes = float(json.load(f)["scan_kernel_hbm_bytes_per_launch"])
+        # HBM-side bytes per scan launch from the separate rocprofv3 --pmc passes (profiles/)
+        for name in ("r02_traffic_split.json", "r01_traffic_split.json"):
+            tp = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(tp):
+                with open(tp) as f:
+                    args.traffic_bytes = float(json.load(f)["scan_kernel_hbm_bytes_per_launch"])
+                break
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
@@ -258,21 +374,27 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if rehearse else "nccl"
         if rehearse:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
 
-    from otter_amd.index import IndexFlatIP, merge_topk
+    from otter_amd.index import IndexFlatIP
+    from otter_amd.sharded import ShardedIndexFlatIP
 
     n, d, nq, k = args.rows, args.dim, args.nq, args.k
-    # shard `rank` of the global synthetic corpus; ids are global (id_base)
+    # shard `rank` of the global synthetic corpus; ids are global (id_base = rank * n)
     xb = gen_rows(n, d, 1234 + rank, dev)
-    index = IndexFlatIP(d, device=local_rank, id_base=rank * n)
-    index.add(xb)
+    six = ShardedIndexFlatIP(d, device=local_rank, exchange_device="cpu" if (world > 1 and rehearse) else None)
+    six.add_shard(xb, rank * n, world * n)
+    index = six.local
     xb_head = xb.cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     check_rows = xb[:65536].clone()
     del xb
@@ -280,24 +402,8 @@ def main():
     q = gen_rows(nq, d, 4321, dev)
     qh = q.cpu().numpy()
 
-    if world > 1:
-        Dg = torch.empty((world * nq, k), dtype=torch.float32, device=dev)
-        Ig = torch.empty((world * nq, k), dtype=torch.int64, device=dev)
-
     def step():
-        D, I = index.search(q, k)
-        if world > 1:
-            if rehearse:    # gloo: stage through the host
-                Dh, Ih = torch.empty((world * nq, k), dtype=torch.float32), torch.empty((world * nq, k), dtype=torch.int64)
-                dist.all_gather_into_tensor(Dh, D.cpu())
-                dist.all_gather_into_tensor(Ih, I.cpu())
-                Dg.copy_(Dh)
-                Ig.copy_(Ih)
-            else:
-                dist.all_gather_into_tensor(Dg, D)
-                dist.all_gather_into_tensor(Ig, I)
-            D, I = merge_topk(Dg.view(world, nq, k), Ig.view(world, nq, k), device=local_rank)
-        return D, I
+        return six.search(q, k)
 
     for _ in range(args.warmup):
         step()
@@ -319,44 +425,113 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    # sanity (outside the timed region): (1) the timed batch's first 64 rows of (D, I) must equal, bit for bit,
-    # what the exact fp32 kernel returns for those queries alone (a 64-query call never takes the coarse path);
-    # (2) the first 65,536 rows re-scored with torch in float64 for 8 queries
-    ok = True
     fallback = index.last_fallback
     refined = index.last_refined
-    if rank == 0 and world > 1:
-        # merged result of the sharded search: sorted, unique global ids in range, and this rank's own shard
-        # result must be a subsequence-by-score of it (every local hit that beats the merged k-th is present)
-        Dl, Il = index.search(q[:64].contiguous(), k)
-        okm = bool((D[:, 1:] <= D[:, :-1]).all().item()) and bool(((I >= 0) & (I < world * n)).all().item())
-        srt = torch.sort(I, dim=1).values
-        okm = okm and bool((srt[:, 1:] != srt[:, :-1]).all().item())
-        for qi in range(64):
-            keep = Il[qi][Dl[qi] > D[qi, -1]]
-            okm = okm and bool(torch.isin(keep, I[qi]).all().item())
-        ok = ok and okm
-    if rank == 0 and world == 1:
-        De, Ie = index.search(q[:64].contiguous(), k)
-        ok = bool(torch.equal(Ie, I[:64])) and bool(torch.equal(De.view(torch.int32), D[:64].view(torch.int32)))
+
+    # ---- sanity, outside the timed region.  The timed batch went through the coarse bf16 pass; the check
+    # queries are searched again in calls of <= 32 queries, which the EXACT fp32 kernel serves (the coarse pass
+    # starts at 33), so the comparison is between two different kernels.
+    nchk = min(64, nq)
+    De = torch.empty((nchk, k), dtype=torch.float32, device=dev)
+    Ie = torch.empty((nchk, k), dtype=torch.int64, device=dev)
+    for lo in range(0, nchk, 32):
+        hi = min(nchk, lo + 32)
+        De[lo:hi], Ie[lo:hi] = index.search(q[lo:hi].contiguous(), k)
+    ok = True
+    checks = {}
+    if world == 1:
+        checks["timed_batch_equals_exact_kernel_bitwise_on_%d_queries" % nchk] = bool(
+            torch.equal(Ie, I[:nchk]) and torch.equal(De.view(torch.int32), D[:nchk].view(torch.int32)))
+    else:
+        # every rank's exact local lists for the check queries, gathered and merged by sorting (torch): the
+        # merged result of the timed sharded search must equal it bit for bit
+        Dl = [torch.empty_like(De.cpu()) for _ in range(world)]
+        Il = [torch.empty_like(Ie.cpu()) for _ in range(world)]
+        if rehearse:
+            dist.all_gather(Dl, De.cpu())
+            dist.all_gather(Il, Ie.cpu())
+        else:
+            Dg = [torch.empty_like(De) for _ in range(world)]
+            Ig = [torch.empty_like(Ie) for _ in range(world)]
+            dist.all_gather(Dg, De)
+            dist.all_gather(Ig, Ie)
+            Dl, Il = [t.cpu() for t in Dg], [t.cpu() for t in Ig]
+        if rank == 0:
+            Dc, Ic = torch.cat(Dl, dim=1), torch.cat(Il, dim=1)          # [nchk, world * k]
+            o1 = torch.argsort(Ic, dim=1, stable=True)
+            Dc, Ic = torch.gather(Dc, 1, o1), torch.gather(Ic, 1, o1)
+            o2 = torch.argsort(-Dc.double(), dim=1, stable=True)[:, :k]
+            Dm, Im = torch.gather(Dc, 1, o2), torch.gather(Ic, 1, o2)
+            Dt, It = D[:nchk].cpu(), I[:nchk].cpu()
+            checks["sharded_result_equals_sorted_merge_of_exact_shard_lists_on_%d_queries" % nchk] = bool(
+                torch.equal(Im, It) and torch.equal(Dm.view(torch.int32), Dt.view(torch.int32)))
+            srt = torch.sort(I, dim=1).values
+            checks["sharded_ids_unique_and_in_range"] = bool(
+                (srt[:, 1:] != srt[:, :-1]).all().item() and ((I >= 0) & (I < world * n)).all().item())
     if rank == 0:
+        # independent arbiter: float64 scores (torch) of the first 65,536 rows for 8 queries
         small = IndexFlatIP(d, device=local_rank)
         small.add(check_rows)
         Ds, Is = small.search(q[:8], k)
         ref = (q[:8].double() @ check_rows.double().T)
         rs, ri = torch.topk(ref, k, dim=1)
         got = torch.gather(ref, 1, Is)
-        ok = ok and bool((got >= rs[:, -1:] - 1e-3).all().item()) and bool(((Ds.double() - got).abs() < 1e-2).all().item())
+        checks["fp64_arbiter_8_queries_x_65536_rows"] = bool(
+            (got >= rs[:, -1:] - 1e-3).all().item() and ((Ds.double() - got).abs() < 1e-2).all().item())
         small.close()
+        ok = all(checks.values())
 
-    index.close()
-    del index, q, check_rows
+    extra = {}
+    if rank == 0 and world == 1 and not args.no_extra:
+        extra["small_batches"] = small_batch_leg(index, q, k, n, d)
+        # PCIe-inclusive rate of the timed workload: host numpy queries in, host numpy (D, I) out
+        index.search(qh, k)
+        t0 = time.perf_counter()
+        reps = max(3, args.steps // 2)
+        for _ in range(reps):
+            index.search(qh, k)
+        pdt = (time.perf_counter() - t0) / reps
+        extra["pcie"] = {"value": nq / pdt, "unit": "queries/s", "ms_per_step": pdt * 1e3,
+                         "note": "same search with pageable host numpy buffers: H2D of %d x %d fp32 queries + D2H of "
+                                 "(D, I) inside the call; never `value`" % (nq, d)}
+
+    exchange = None if world == 1 else "%s of packed (id, score) candidates, %d bytes sent per rank and step" % (
+        six.last_exchange, six.last_exchange_bytes)
+    six.local.close()
+    del index, six, check_rows
     torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not args.no_extra and (n, d) == (1000000, 768):
+        # the dimension the reference's script actually searches (three-cat embeddings, d = 768 * 3,
+        # scripts/eval_ottqa_retrieval.py:74), same rows / queries / k
+        d3 = 2304
+        x3 = gen_rows(n, d3, 2234, dev)
+        ix3 = IndexFlatIP(d3, device=local_rank)
+        ix3.add(x3)
+        del x3
+        torch.cuda.empty_cache()
+        q3 = gen_rows(nq, d3, 5321, dev)
+        s3, w3 = timed_search(ix3, q3, k, max(4, args.steps // 3), 2)
+        D3, I3 = ix3.search(q3, k)
+        Dx, Ix = ix3.search(q3[:32].contiguous(), k)
+        ok3 = bool(torch.equal(Ix, I3[:32]) and torch.equal(Dx.view(torch.int32), D3[:32].view(torch.int32)))
+        f3 = 2.0 * n * d3 * nq
+        extra["dim2304"] = {"value": nq / (w3 * 1e-3), "unit": "queries/s", "ms_per_step": w3, "scan_ms": s3,
+                            "rows": n, "dim": d3, "nq": nq, "k": k,
+                            "f32_equivalent_tflops": f3 / (w3 * 1e-3) / 1e12,
+                            "coarse_pass_bf16_tflops_scan": f3 / (s3 * 1e-3) / 1e12,
+                            "bf16_mfma_frac_scan": f3 / (s3 * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                            "timed_batch_equals_exact_kernel_bitwise_on_32_queries": ok3,
+                            "exact_fallback_queries": ix3.last_fallback, "refined_queries": ix3.last_refined}
+        ok = ok and ok3
+        ix3.close()
+        del ix3, q3
+        torch.cuda.empty_cache()
+
     enc = None
     if not args.no_encode:
-        enc = encode_leg(rank, world, local_rank, dist, max(4, args.steps // 2), min(3, max(1, args.warmup)), args.encode_batch,
-                         world == 1 and not args.no_cpu_baseline)
+        enc = encode_leg(rank, world, local_rank, dist, max(4, args.steps // 2), min(3, max(1, args.warmup)),
+                         args.encode_batch, world == 1 and not args.no_cpu_baseline, rehearse)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -374,11 +549,11 @@ def main():
                          {1: "x_hi*q_hi", 2: "x_hi*q_hi + x_lo*q_hi", 3: "x_hi*q_hi + x_hi*q_lo + x_lo*q_hi"}[nprod]) +
                      "kernel_ms is one HIP-event bracket per search on the launch stream = %d dispatches of this kernel "
                      "(threshold-seeding sample levels over the first 1/4 of the tiles, each started from the threshold "
-                     "of the levels before it, then the main scan) and the ~0.1 ms merges between them: rocprof's "
+                     "of the levels before it, then the main scan) and the merges between them: rocprof's "
                      "TotalDurationNs of scan16_kernel / steps + those merges" % scan16_dispatches(n, nq, k, d, nprod))
         else:
             kernel_flops, peak = flops, PEAK_FP32_MFMA_TFLOPS
-            kname = "scan_kernel<4,2,2,2,32,3,8> (256x128 tile, fp32 v_mfma_f32_32x32x2_f32 + fused top-k filter)"
+            kname = "scan_kernel (fp32 v_mfma_f32_32x32x2_f32 + fused top-k filter)"
         achieved = kernel_flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
         out = {
             "metric": "exact top-100 MIPS queries/s over 768-d corpus; corpus encode blocks/s",
@@ -395,9 +570,12 @@ def main():
                      if split else "f32",
             "data": "synthetic",
             "config": {"workload": "configs[1]: exact top-%d IP search, %d-query batch over %dx%d fp32 corpus "
-                                   "per GPU (row-sharded at N>1, RCCL all-gather + GPU merge)" % (k, nq, n, d),
+                                   "per GPU (row-sharded at N>1: ShardedIndexFlatIP, one packed all-gather + GPU merge)"
+                                   % (k, nq, n, d),
                        "rows_per_gpu": n, "dim": d, "nq": nq, "k": k,
-                       "value_counts": "1M-row query scans per second over all ranks (= queries/s at N=1)"},
+                       "value_counts": "1M-row query scans per second over all ranks (= queries/s at N=1)",
+                       "ranks": world, "backend": backend,
+                       "exchange": exchange},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
                          "traffic": args.traffic_bytes,
@@ -415,16 +593,19 @@ def main():
                          "hbm_frac_if_bandwidth_bound": (float(n) * d * 4 / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS)
                          if kern_ms > 0 else 0.0},
             "self_check": "ok" if ok else "FAILED",
+            "self_checks": checks,
         }
+        out.update(extra)
         if enc is not None:
             out["encode"] = enc
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lambda r: xb_head[:r], qh, k, n)
         print(json.dumps(out), flush=True)
-        if not ok:
-            sys.exit(1)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and not ok:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

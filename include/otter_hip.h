@@ -19,8 +19,14 @@
  *     HBM copy of the corpus; an encoder owns its private HBM copy of the weights.
  *   - handles are not thread-safe; one handle per device.
  *   - `stream` is a hipStream_t passed as void* (NULL = the device's default
- *     stream).  Calls with host buffers synchronise the stream before returning;
- *     calls with device buffers only enqueue work.
+ *     stream).  Calls with host buffers synchronise the stream before returning.
+ *     Calls with device buffers enqueue their work on the stream and return, with
+ *     these exceptions, which also wait for it: otter_index_search of 33 and more
+ *     queries on an OTTER_F32 index of 65,536 and more rows (one 4-byte read-back
+ *     per pass of the coarse search: how many queries still lack a proof; usually
+ *     one pass), otter_index_search_subset (validation of the id lists),
+ *     otter_index_add when the allocation grows, and otter_index_timing.  A
+ *     search of at most 32 queries only enqueues.
  *   - no torch types anywhere; plain pointers and sizes only.
  */
 #ifndef OTTER_HIP_H
@@ -122,11 +128,18 @@ void otter_index_destroy(otter_index* ix);
 int otter_index_set_timing(otter_index* ix, int enable);
 int otter_index_timing(otter_index* ix, double* scan_ms, int64_t* scan_launches);
 
+/* State of the coarse pass of an index (no counterpart in the reference): 0 = its bf16 planes are not built yet
+ * (they are built by the first search of 33 and more queries: once the corpus' bytes again for the hi/lo planes,
+ * half of them again for the one-product plane), 1 = built and in use, 2 = HBM had no room for them, so the exact
+ * fp32 kernel serves every batch size (about 1/6 of the rate at 2,214 queries; a note goes to stderr once),
+ * 3 = not an OTTER_F32 index. */
+int otter_index_coarse_state(const otter_index* ix);
+
 /* Diagnostic (no counterpart in the reference).  Large query batches on an OTTER_F32 index run a
  * coarse pass on the bf16 matrix cores (hi/lo split of both operands), re-score its k + margin
  * candidates with the exact float32 chain and PROVE per query that no other row can reach the top
  * k; a query without a proof is searched again by the exact float32 kernel.  Returns how many
- * queries of the last search() took that second route (0 in the usual case). */
+ * queries of the last search() call (summed over its 16,384-query chunks) took that second route (0 in the usual case). */
 int64_t otter_index_last_fallback(const otter_index* ix);
 /* Queries of the last search() that the two-product coarse pass could not prove and that were searched again
  * with the three-product pass (or, if fewer than 33, by the exact kernel); 0 on the other paths. */

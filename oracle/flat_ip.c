@@ -26,6 +26,9 @@
  *           k visited as 8-groups in the order 0,4,1,5,2,6,3,7 (the k-pairing of
  *           v_mfma_f32_32x32x2_f32 fed with 16-byte fragments) — bit-exact oracle
  *   mode 2  float64 accumulation (arbiter for near-ties), score rounded to float32
+ *   mode 3  eight float32 partial sums over k mod 8, added pairwise at the end: the shape of a
+ *           SIMD inner-product loop such as faiss' fvec_inner_product (AVX2, 8 lanes) -- used as
+ *           the timed "reference-style" CPU baseline (nq = 1 per scan), never as a parity target
  *
  * Build: gcc -O2 -mavx2 -mfma -fopenmp -shared -fPIC oracle/flat_ip.c -o oracle/liboracle_flat_ip.so -lm
  */
@@ -96,6 +99,15 @@ static inline float dot_mode2(const float* x, const float* q, int d) {
     return (float)acc;
 }
 
+static inline float dot_mode3(const float* x, const float* q, int d) {
+    float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int j = 0;
+    for (; j + 8 <= d; j += 8)
+        for (int t = 0; t < 8; ++t) p[t] += x[j + t] * q[j + t];
+    for (int t = 0; j < d; ++j, ++t) p[t] += x[j] * q[j];
+    return ((p[0] + p[4]) + (p[2] + p[6])) + ((p[1] + p[5]) + (p[3] + p[7]));
+}
+
 /* returns 0 on success */
 int oracle_flat_ip_search(const float* xb, int64_t n, int d, const float* q, int64_t nq, int k,
                           float* D, int64_t* I, int mode, int64_t id_base, int nthreads) {
@@ -112,7 +124,7 @@ int oracle_flat_ip_search(const float* xb, int64_t n, int d, const float* q, int
         const float* qq = q + iq * (int64_t)d;
         for (int64_t i = 0; i < n; ++i) {
             const float* x = xb + i * (int64_t)d;
-            float s = mode == 1 ? dot_mode1(x, qq, d) : mode == 2 ? dot_mode2(x, qq, d) : dot_mode0(x, qq, d);
+            float s = mode == 1 ? dot_mode1(x, qq, d) : mode == 2 ? dot_mode2(x, qq, d) : mode == 3 ? dot_mode3(x, qq, d) : dot_mode0(x, qq, d);
             cand_t c = {s, i};
             if (hn < k) {
                 heap[hn++] = c;

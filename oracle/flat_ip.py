@@ -24,7 +24,7 @@ def build(force=False):
     """Compile oracle/flat_ip.c with gcc (also called from __graft_entry__.build)."""
     src = os.path.join(_HERE, "flat_ip.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O2", "-mavx2", "-mfma", "-fopenmp", "-shared", "-fPIC",
+        subprocess.check_call(["gcc", "-O3", "-mavx2", "-mfma", "-fopenmp", "-shared", "-fPIC",
                                src, "-o", _SO, "-lm"])
     return _SO
 
@@ -51,7 +51,7 @@ def _c():
     return _lib
 
 
-MODE_PLAIN, MODE_GPU_ORDER, MODE_F64 = 0, 1, 2
+MODE_PLAIN, MODE_GPU_ORDER, MODE_F64, MODE_SIMD8 = 0, 1, 2, 3
 
 
 def search_c(xb, q, k, mode=MODE_GPU_ORDER, id_base=0, nthreads=0):

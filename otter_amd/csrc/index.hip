@@ -972,12 +972,15 @@ __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
             }
         }
     }
-    // counts: invalid candidates (id < 0) are the tail of the coarse list
-    if (threadIdx.x == 0) {
+    // counts: invalid candidates (id < 0) are the tail of the list (one wave counts with ballots)
+    if (wave == 0) {
         int valid = 0;
-        for (int i = 0; i < a.kc; ++i) valid += a.Ic[(size_t)q * a.kc + i] >= 0;
+        for (int i0 = 0; i0 < a.kc; i0 += 64) {
+            const int i = i0 + lane;
+            valid += __popcll(__ballot(i < a.kc && a.Ic[(size_t)q * a.kc + i] >= 0));
+        }
         const int S2 = (a.kc + a.k - 1) / a.k;
-        for (int s = 0; s < S2; ++s) a.out_cnt[(size_t)s * a.nq_pad + q] = (u32)max(0, min(a.k, valid - s * a.k));
+        for (int s = lane; s < S2; s += 64) a.out_cnt[(size_t)s * a.nq_pad + q] = (u32)max(0, min(a.k, valid - s * a.k));
     }
 }
 
@@ -1006,6 +1009,50 @@ __global__ void margin_check_kernel(const float* Dexact, const float* Dcoarse, c
     }
     flags[q] = ok ? 0u : 1u;
     if (!ok) atomicAdd(nflag, 1u);
+}
+
+// Unproven queries of a coarse pass: `which` lists them (ascending).  gather: rows of q -> a dense batch;
+// scatter: the dense batch's result rows back to their places in (D, I).
+__global__ void compact_flags_kernel(const u32* __restrict__ flags, long long nq, int* __restrict__ which) {
+    // one workgroup of 1024 threads: order-preserving compaction of the flagged query numbers
+    __shared__ int s_base, s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (long long q0 = 0; q0 < nq; q0 += 1024) {
+        const long long q = q0 + tid;
+        const bool f = q < nq && flags[q] != 0u;
+        const u64 m = __ballot(f);
+        if (lane == 0) s_w[wave] = __popcll(m);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_w[w];
+        if (f) which[off + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0))] = (int)q;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += s_w[w];
+            s_base += t;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ which, float* __restrict__ dst,
+                                   int d) {
+    const float* s = src + (size_t)which[blockIdx.x] * d;
+    float* o = dst + (size_t)blockIdx.x * d;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) o[c] = s[c];
+}
+
+__global__ void scatter_results_kernel(const float* __restrict__ Ds, const long long* __restrict__ Is,
+                                       const int* __restrict__ which, float* __restrict__ D, long long* __restrict__ I,
+                                       int k) {
+    const size_t so = (size_t)blockIdx.x * k, to = (size_t)which[blockIdx.x] * k;
+    for (int c = threadIdx.x; c < k; c += blockDim.x) {
+        D[to + c] = Ds[so + c];
+        I[to + c] = Is[so + c];
+    }
 }
 
 // queries -> zero-padded [nq_pad][ld]
@@ -1391,7 +1438,7 @@ struct otter_index {
     long long last_fallback = 0;    // queries of the last split search that went to the exact kernel
     long long last_refined = 0;     // ... that the two-product pass could not prove (three-product pass or exact kernel)
     bool two_prod_off = false;      // the two-product pass failed for > 1/4 of a batch: this corpus starts with three
-    otter::DevBuf qres2, fb2_q, fb2_D, fb2_I;
+    otter::DevBuf qres2, fb2_q, fb2_D, fb2_I, fb_w, fb2_w, fb3_w;
     // one-product pass (stage 0): a third copy of the corpus, bf16 hi values only (half the fp32 bytes), the
     // largest |x - x_hi| over its rows for the error bound, and the rounded queries
     otter::DevBuf xh, xres2, xrmax, qh16, fb3_q, fb3_D, fb3_I;
@@ -1404,7 +1451,29 @@ struct otter_index {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
 };
 
+constexpr int NA_MAX_STRIPS = 256;
+
 namespace {
+
+// Where a search's device scratch comes from: the index's grow-only buffers (may call hipMalloc), or a fixed
+// region handed out by a bump pointer (never allocates; running out is an error).
+struct Scratch {
+    unsigned char* fixed = nullptr;
+    size_t fixed_bytes = 0, used = 0;
+    int get(otter::DevBuf& b, size_t bytes, void** out) {
+        if (!fixed) {
+            const int rc = b.reserve(bytes);
+            *out = b.p;
+            return rc;
+        }
+        const size_t at = (used + 255) & ~(size_t)255;
+        if (at + bytes > fixed_bytes)
+            return set_err(OTTER_EINVAL, "search_noalloc: this shape needs more than the %zu-byte static scratch", fixed_bytes);
+        *out = fixed + at;
+        used = at + bytes;
+        return OTTER_OK;
+    }
+};
 
 int index_reserve_rows(otter_index* ix, long long need_rows, hipStream_t st) {
     if (need_rows <= ix->cap_rows) return OTTER_OK;
@@ -1446,7 +1515,9 @@ int index_reserve_rows(otter_index* ix, long long need_rows, hipStream_t st) {
 // itself) and the score key of each query's k-th best in thr_out.
 int run_merge(otter_index* ix, const u64* in, const u32* in_cnt, int cap_in, int S_in, long long nq, long long nq_pad,
               int k, bool final, float* D, long long* I, const u64* ex, const u32* ex_cnt, u64* list_out,
-              u32* list_cnt, u32* thr_out, hipStream_t st, int take_first = 0) {
+              u32* list_cnt, u32* thr_out, hipStream_t st, int take_first = 0, Scratch* sc = nullptr) {
+    Scratch own;
+    if (!sc) sc = &own;
     int take = take_first > 0 ? take_first : k;      // first level only; later levels read lists of <= k
     int fan = std::min(MERGE_MAX_STRIPS, std::max(2, (MAX_SELECT - (ex ? k : 0)) / take));
     int pp = 0, rc;
@@ -1479,10 +1550,11 @@ int run_merge(otter_index* ix, const u64* in, const u32* in_cnt, int cap_in, int
                 ma.out_cnt = list_cnt;
                 ma.thr_out = thr_out;
             } else {
-                if ((rc = ix->lvl[pp].reserve((size_t)S_out * nq_pad * k * sizeof(u64)))) return rc;
-                if ((rc = ix->lvlcnt[pp].reserve((size_t)S_out * nq_pad * sizeof(u32)))) return rc;
-                ma.out = (u64*)ix->lvl[pp].p;
-                ma.out_cnt = (u32*)ix->lvlcnt[pp].p;
+                void *lp = nullptr, *lc = nullptr;
+                if ((rc = sc->get(ix->lvl[pp], (size_t)S_out * nq_pad * k * sizeof(u64), &lp))) return rc;
+                if ((rc = sc->get(ix->lvlcnt[pp], (size_t)S_out * nq_pad * sizeof(u32), &lc))) return rc;
+                ma.out = (u64*)lp;
+                ma.out_cnt = (u32*)lc;
             }
         }
         const size_t lds = (size_t)ma.npad * sizeof(u64) + (size_t)(MERGE_MAX_STRIPS + 4 + 32 + 4) * sizeof(int);
@@ -1507,6 +1579,8 @@ int run_merge(otter_index* ix, const u64* in, const u32* in_cnt, int cap_in, int
     return OTTER_OK;
 }
 
+struct Scratch;
+int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st, Scratch* sc);
 int search_chunk_bf16(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st);
 int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st,
                        int mode, bool first);
@@ -1515,9 +1589,12 @@ int ensure_split_planes(otter_index* ix, hipStream_t st);
 int ensure_hi_plane(otter_index* ix, hipStream_t st);
 
 // one scan + merge over queries [qd, qd + nq) (device pointers), results to device D/I
-int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st) {
+int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st,
+                 Scratch* sc = nullptr) {
+    Scratch own;
+    if (!sc) sc = &own;
     if (ix->dtype == OTTER_BF16) return search_chunk_bf16(ix, qd, nq, k, D, I, st);
-    {
+    if (!sc->fixed) {
         // MFMA-bound batches on a large corpus: coarse pass on the bf16 matrix cores + exact re-scoring
         static const char* no_split_env = getenv("OTTER_NO_SPLIT");
         static const char* split_min_env = getenv("OTTER_SPLIT_MIN_NQ");   // tuning runs only
@@ -1536,8 +1613,6 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
                     if (rh < 0) return rh;
                     if (rh == 0) mode = 3;
                 }
-                ix->last_fallback = 0;
-                ix->last_refined = 0;
                 return search_chunk_split(ix, qd, nq, k, D, I, st, mode, true);
             }
         }
@@ -1562,30 +1637,32 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
     const int main_tiles = all_tiles - sample_tiles;
     int strips = std::max(1, ix->ncu / qtiles);
     strips = std::min(strips, main_tiles);
-    // few enough sample strips for a one-level merge (k <= 128 on this path's sizes: fan >= 64)
+    if (sc->fixed) strips = std::min(strips, NA_MAX_STRIPS);
+    // few enough sample strips for a one-level merge (fan >= 64 up to k = 126; beyond, run_merge adds a level)
     int strips_s = sample ? std::min(std::min(std::max(1, ix->ncu / qtiles), sample_tiles), 64) : 0;
 
-    if ((rc = ix->qpad.reserve((size_t)nq_pad * ix->ld * sizeof(float)))) return rc;
-    if ((rc = ix->cand.reserve((size_t)std::max(strips, strips_s) * nq_pad * cfg.cap * sizeof(u64)))) return rc;
-    if ((rc = ix->cnt.reserve((size_t)std::max(strips, strips_s) * nq_pad * sizeof(u32)))) return rc;
+    void *w_qpad, *w_cand, *w_cnt, *w_smp = nullptr, *w_smpcnt = nullptr, *w_thr0 = nullptr;
+    if ((rc = sc->get(ix->qpad, (size_t)nq_pad * ix->ld * sizeof(float), &w_qpad))) return rc;
+    if ((rc = sc->get(ix->cand, (size_t)std::max(strips, strips_s) * nq_pad * cfg.cap * sizeof(u64), &w_cand))) return rc;
+    if ((rc = sc->get(ix->cnt, (size_t)std::max(strips, strips_s) * nq_pad * sizeof(u32), &w_cnt))) return rc;
     if (sample) {
-        if ((rc = ix->smp.reserve((size_t)nq_pad * k * sizeof(u64)))) return rc;
-        if ((rc = ix->smpcnt.reserve((size_t)nq_pad * sizeof(u32)))) return rc;
-        if ((rc = ix->thr0.reserve((size_t)nq_pad * sizeof(u32)))) return rc;
+        if ((rc = sc->get(ix->smp, (size_t)nq_pad * k * sizeof(u64), &w_smp))) return rc;
+        if ((rc = sc->get(ix->smpcnt, (size_t)nq_pad * sizeof(u32), &w_smpcnt))) return rc;
+        if ((rc = sc->get(ix->thr0, (size_t)nq_pad * sizeof(u32), &w_thr0))) return rc;
     }
 
     {
         const long long total = nq_pad * ix->ld;
         const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
-        hipLaunchKernelGGL(pad_rows_kernel, dim3(grid), dim3(256), 0, st, qd, (float*)ix->qpad.p, nq, nq_pad, ix->d,
+        hipLaunchKernelGGL(pad_rows_kernel, dim3(grid), dim3(256), 0, st, qd, (float*)w_qpad, nq, nq_pad, ix->d,
                            ix->ld);
     }
 
     ScanArgs sa;
     sa.X = ix->x;
-    sa.Q = (const float*)ix->qpad.p;
-    sa.cand = (u64*)ix->cand.p;
-    sa.cnt = (u32*)ix->cnt.p;
+    sa.Q = (const float*)w_qpad;
+    sa.cand = (u64*)w_cand;
+    sa.cnt = (u32*)w_cnt;
     sa.n = ix->n;
     sa.ld = ix->ld;
     sa.nq = (int)nq;
@@ -1596,7 +1673,7 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
     static const char* ord = getenv("OTTER_SCAN_ORDER");
     sa.order = ord ? (ord[0] == '1') : 1;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-    const bool timed = ix->timing && ix->ev_pending.size() < 4096;
+    const bool timed = ix->timing && ix->ev_pending.size() < 4096 && !sc->fixed;   // (events are created on demand)
     if (timed) {
         if (!ix->ev_free.empty()) {
             ev = ix->ev_free.back();
@@ -1614,15 +1691,15 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
         sa.thr0 = nullptr;
         cfg.launch(sa, qtiles * strips_s, cfg.lds, st);
         OTTER_HIP_TRY(hipGetLastError());
-        if ((rc = run_merge(ix, (const u64*)ix->cand.p, (const u32*)ix->cnt.p, cfg.cap, strips_s, nq, nq_pad, k, false,
-                            nullptr, nullptr, nullptr, nullptr, (u64*)ix->smp.p, (u32*)ix->smpcnt.p, (u32*)ix->thr0.p,
-                            st)))
+        if ((rc = run_merge(ix, (const u64*)w_cand, (const u32*)w_cnt, cfg.cap, strips_s, nq, nq_pad, k, false,
+                            nullptr, nullptr, nullptr, nullptr, (u64*)w_smp, (u32*)w_smpcnt, (u32*)w_thr0,
+                            st, 0, sc)))
             return rc;
     }
     sa.strips = strips;
     sa.total_tiles = main_tiles;
     sa.tile_begin = sample_tiles;
-    sa.thr0 = sample ? (const u32*)ix->thr0.p : nullptr;
+    sa.thr0 = sample ? (const u32*)w_thr0 : nullptr;
 #ifdef SCAN_DIAG
     static otter::DevBuf dbgbuf;
     const size_t dbg_n = (size_t)qtiles * strips * 8 * 4;
@@ -1653,9 +1730,9 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
                     nwv, tot / nwv, mx, wait / nwv, epi / nwv, tot / stages, wait / stages);
     }
 #endif
-    return run_merge(ix, (const u64*)ix->cand.p, (const u32*)ix->cnt.p, cfg.cap, strips, nq, nq_pad, k, true, D, I,
-                     sample ? (const u64*)ix->smp.p : nullptr, sample ? (const u32*)ix->smpcnt.p : nullptr, nullptr,
-                     nullptr, nullptr, st);
+    return run_merge(ix, (const u64*)w_cand, (const u32*)w_cnt, cfg.cap, strips, nq, nq_pad, k, true, D, I,
+                     sample ? (const u64*)w_smp : nullptr, sample ? (const u32*)w_smpcnt : nullptr, nullptr,
+                     nullptr, nullptr, st, 0, sc);
 }
 
 // common part of the two bf16-MFMA searches: scan `Xk` (bf16 planes of ldk elements per row) for the
@@ -1762,7 +1839,10 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
             return rc;
         done_tiles += lv_tiles[lv];
     }
-    if (getenv("OTTER_DIAG_NOHIT") && sample) (void)hipMemsetAsync(ix->thr0.p, 0xFF, (size_t)nq_pad * 4, st);  // DIAG ONLY
+#ifdef SCAN_DIAG
+    // ablation: an unreachable threshold (no appends in the main scan; results are garbage)
+    if (getenv("OTTER_DIAG_NOHIT") && sample) (void)hipMemsetAsync(ix->thr0.p, 0xFF, (size_t)nq_pad * 4, st);
+#endif
     sa.skip_final = 0;
     sa.strips = strips;
     sa.total_tiles = main_tiles;
@@ -1811,6 +1891,10 @@ int ensure_split_planes(otter_index* ix, hipStream_t st) {
             (void)hipGetLastError();
             ix->xs.p = nullptr;
             ix->xs_failed = true;           // not enough HBM for the planes: the exact kernel serves every batch
+            fprintf(stderr, "[libotter_hip] note: no room in HBM for the bf16 planes of this %lld x %d index (%.1f GB more); "
+                            "query batches of 33 and more are served by the exact fp32 kernel at about 1/6 of the "
+                            "coarse pass's rate (otter_index_coarse_state() reports 2)\n",
+                    ix->n, ix->d, (double)ix->cap_rows * ix->ld * 4 / 1e9);
             return 1;
         }
         ix->xs.bytes = (size_t)ix->cap_rows * ix->ld * 4;
@@ -1872,8 +1956,6 @@ int ensure_hi_plane(otter_index* ix, hipStream_t st) {
     }
     return OTTER_OK;
 }
-
-int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st);
 
 // Exact fp32 search of a large query batch through the bf16 matrix cores: coarse top-kc on hi/lo bf16
 // planes, exact re-scoring of those candidates with scan_kernel's fp32 chain, and a per-query proof that
@@ -1956,15 +2038,16 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
                        mode >= 2 ? (const float*)ix->qres2.p : (const float*)nullptr,
                        mode == 3 ? (const u32*)ix->xrmax.p : (const u32*)nullptr);
     OTTER_HIP_TRY(hipGetLastError());
-    // the one host round trip of this pass: how many queries are left without a proof
-    std::vector<u32> hflags((size_t)nq + 1);
-    OTTER_HIP_TRY(hipMemcpyAsync(hflags.data(), flags, (size_t)(nq + 1) * sizeof(u32), hipMemcpyDeviceToHost, st));
+    // the one host round trip of this pass (4 bytes): how many queries are left without a proof.  The
+    // stream is synchronised here -- once per pass of a large-batch search (see include/otter_hip.h).
+    u32 nf_host = 0;
+    OTTER_HIP_TRY(hipMemcpyAsync(&nf_host, flags + nq, sizeof(u32), hipMemcpyDeviceToHost, st));
     OTTER_HIP_TRY(hipStreamSynchronize(st));
-    const long long nf = hflags[(size_t)nq];
-    if (mode >= 2 && first) ix->last_refined = nf;
+    const long long nf = nf_host;
+    if (mode >= 2 && first) ix->last_refined += nf;
     if (mode == 3 && nf * 4 > nq) ix->one_prod_off = true;
     if (mode == 2 && nf * 4 > nq) ix->two_prod_off = true;
-    if (mode == 1) ix->last_fallback = nf;
+    if (mode == 1) ix->last_fallback += nf;
     if (nf == 0) return OTTER_OK;
     // unproven queries: gather them, search them again one level down, scatter the rows back
     otter::DevBuf& bq = mode == 3 ? ix->fb3_q : mode == 2 ? ix->fb2_q : ix->fb_q;
@@ -1973,28 +2056,24 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
     if ((rc = bq.reserve((size_t)nf * ix->d * sizeof(float)))) return rc;
     if ((rc = bD.reserve((size_t)nf * k * sizeof(float)))) return rc;
     if ((rc = bI.reserve((size_t)nf * k * sizeof(long long)))) return rc;
-    std::vector<long long> which;
-    for (long long q = 0; q < nq; ++q)
-        if (hflags[(size_t)q]) which.push_back(q);
-    for (size_t i = 0; i < which.size(); ++i)
-        OTTER_HIP_TRY(hipMemcpyAsync((float*)bq.p + i * ix->d, qd + (size_t)which[i] * ix->d,
-                                     (size_t)ix->d * sizeof(float), hipMemcpyDeviceToDevice, st));
+    otter::DevBuf& bw = mode == 3 ? ix->fb3_w : mode == 2 ? ix->fb2_w : ix->fb_w;
+    if ((rc = bw.reserve((size_t)nq * sizeof(int)))) return rc;
+    hipLaunchKernelGGL(compact_flags_kernel, dim3(1), dim3(1024), 0, st, (const u32*)flags, nq, (int*)bw.p);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nf), dim3(256), 0, st, qd, (const int*)bw.p, (float*)bq.p, ix->d);
+    OTTER_HIP_TRY(hipGetLastError());
     if (mode >= 2 && nf >= 33) {
         const int next = (mode == 3 && !ix->two_prod_off && split_kc(k, 2, ix->d) <= S16_MAX_K) ? 2 : 1;
         rc = search_chunk_split(ix, (const float*)bq.p, nf, k, (float*)bD.p, (long long*)bI.p, st, next, false);
     } else {
-        if (mode >= 2) ix->last_fallback = nf;
+        if (mode >= 2) ix->last_fallback += nf;
         ix->no_split = true;
-        rc = search_chunk(ix, (const float*)bq.p, nf, k, (float*)bD.p, (long long*)bI.p, st);
+        rc = search_chunk(ix, (const float*)bq.p, nf, k, (float*)bD.p, (long long*)bI.p, st, nullptr);
         ix->no_split = false;
     }
     if (rc) return rc;
-    for (size_t i = 0; i < which.size(); ++i) {
-        OTTER_HIP_TRY(hipMemcpyAsync(D + (size_t)which[i] * k, (float*)bD.p + i * k, (size_t)k * sizeof(float),
-                                     hipMemcpyDeviceToDevice, st));
-        OTTER_HIP_TRY(hipMemcpyAsync(I + (size_t)which[i] * k, (long long*)bI.p + i * k, (size_t)k * sizeof(long long),
-                                     hipMemcpyDeviceToDevice, st));
-    }
+    hipLaunchKernelGGL(scatter_results_kernel, dim3((unsigned)nf), dim3(256), 0, st, (const float*)bD.p,
+                       (const long long*)bI.p, (const int*)bw.p, D, I, k);
+    OTTER_HIP_TRY(hipGetLastError());
     return OTTER_OK;
 }
 
@@ -2109,6 +2188,8 @@ int otter_index_search(otter_index* ix, const void* q, int64_t nq, int k, float*
         Id = (long long*)ix->io_I.p;
     }
 
+    ix->last_fallback = 0;      // diagnostic counters of this call, summed over its query chunks
+    ix->last_refined = 0;
     if (ix->n == 0) {
         const long long total = (long long)nq * k;
         hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)),
@@ -2155,7 +2236,7 @@ int otter_index_search_subset(otter_index* ix, const void* q, int64_t nq, int k,
     if ((rc = ix->flags.reserve(2 * sizeof(u32)))) return rc;
     for (long long q0 = 0; q0 < nq; q0 += chunk) {
         const long long c = std::min<long long>(chunk, nq - q0);
-        const long long c_pad = round_up64(c, S16_BQ);
+        const long long c_pad = c;      // row stride of the per-query scratch lists: nothing here reads a padded query
         if ((rc = ix->qpad.reserve((size_t)c_pad * ix->ld * sizeof(float)))) return rc;
         if ((rc = ix->cI.reserve((size_t)c * m * sizeof(long long)))) return rc;
         if ((rc = ix->rs.reserve((size_t)S2 * c_pad * k * sizeof(u64)))) return rc;
@@ -2313,6 +2394,13 @@ int otter_index_timing(otter_index* ix, double* scan_ms, int64_t* scan_launches)
     return OTTER_OK;
 }
 
+int otter_index_coarse_state(const otter_index* ix) {
+    if (!ix) return set_err(OTTER_EINVAL, "coarse_state: index is NULL");
+    if (ix->dtype != OTTER_F32) return 3;
+    if (ix->xs_failed) return 2;
+    return ix->xs_rows >= ix->n && ix->n > 0 && ix->xs.p ? 1 : 0;
+}
+
 int64_t otter_index_last_fallback(const otter_index* ix) { return ix ? ix->last_fallback : -1; }
 int64_t otter_index_last_refined(const otter_index* ix) { return ix ? ix->last_refined : -1; }
 
@@ -2325,7 +2413,7 @@ void otter_index_destroy(otter_index* ix) {
     if (ix->x16) (void)hipFree(ix->x16);
     for (otter::DevBuf* b : {&ix->xs, &ix->xnorm2, &ix->xnmax, &ix->qs, &ix->qnorm2, &ix->cD, &ix->cI, &ix->rs,
                              &ix->rscnt, &ix->flags, &ix->fb_q, &ix->fb_D, &ix->fb_I, &ix->qres2, &ix->fb2_q, &ix->fb2_D, &ix->fb2_I, &ix->xh, &ix->xres2, &ix->xrmax, &ix->qh16,
-                             &ix->fb3_q, &ix->fb3_D, &ix->fb3_I})
+                             &ix->fb3_q, &ix->fb3_D, &ix->fb3_I, &ix->fb_w, &ix->fb2_w, &ix->fb3_w})
         b->release();
     ix->qpad.release();
     ix->cand.release();

@@ -13,16 +13,142 @@ import os
 import numpy as np
 import torch
 
-from .encoder import move_to_cuda
+from .encoder import move_to_cuda  # noqa: F401  (re-exported: the reference's predict() calls it per batch)
 
 
-def predict(model, eval_dataloader, to_cpu=True):
+class _PipeSlot:
+    """One of the two in-flight batches of predict(): pinned host staging for the token tensors, their
+    device copies, a pinned host buffer for the embeddings and the events that order the three streams."""
+
+    def __init__(self, use_cuda):
+        self.use_cuda = use_cuda
+        self.pin = {}            # name -> flat pinned int64 buffer (grow-only)
+        self.dev = {}            # name -> flat device int64 buffer (grow-only)
+        self.out_pin = None      # flat pinned float32 buffer
+        self.out_dev = None      # the forward's result, kept alive until its download ran
+        self.rows = 0
+        self.dim = 0
+        self.busy = False
+        if use_cuda:
+            self.ev_h2d = torch.cuda.Event()
+            self.ev_fwd = torch.cuda.Event()
+            self.ev_d2h = torch.cuda.Event()
+
+    def _flat(self, store, name, numel, dtype, pinned, device=None):
+        t = store.get(name)
+        if t is None or t.numel() < numel:
+            if pinned:
+                t = torch.empty((numel,), dtype=dtype, pin_memory=self.use_cuda)
+            else:
+                t = torch.empty((numel,), dtype=dtype, device=device)
+            store[name] = t
+        return t
+
+    def upload(self, batch, device, copy_stream):
+        """Host batch dict -> device batch dict; the copies are enqueued on copy_stream."""
+        if self.use_cuda:
+            self.ev_h2d.synchronize()     # the pinned staging of this slot's previous batch has been read
+        out = {}
+        for name, t in batch.items():
+            if not torch.is_tensor(t):
+                out[name] = t
+                continue
+            if t.is_cuda:                 # already resident: nothing to stage
+                out[name] = t
+                continue
+            src = t.to(torch.int64).contiguous() if t.dtype != torch.int64 else t.contiguous()
+            if not self.use_cuda:
+                out[name] = src
+                continue
+            n = src.numel()
+            pin = self._flat(self.pin, name, n, torch.int64, True)[:n].view(src.shape)
+            pin.copy_(src)
+            devt = self._flat(self.dev, name, n, torch.int64, False, device)[:n].view(src.shape)
+            with torch.cuda.stream(copy_stream):
+                devt.copy_(pin, non_blocking=True)
+            out[name] = devt
+        if self.use_cuda:
+            self.ev_h2d.record(copy_stream)
+        return out
+
+    def download(self, embed, down_stream, to_cpu):
+        """Enqueue the device -> pinned host copy of one batch's embeddings behind its forward."""
+        self.rows, self.dim = int(embed.shape[0]), int(embed.shape[1])
+        self.out_dev = embed
+        self.busy = True
+        if not (to_cpu and self.use_cuda and embed.is_cuda):
+            return
+        n = embed.numel()
+        if self.out_pin is None or self.out_pin.numel() < n:
+            self.out_pin = torch.empty((n,), dtype=torch.float32, pin_memory=True)
+        self.ev_fwd.record(torch.cuda.current_stream(embed.device))
+        with torch.cuda.stream(down_stream):
+            down_stream.wait_event(self.ev_fwd)
+            self.out_pin[:n].view(self.rows, self.dim).copy_(embed, non_blocking=True)
+            self.ev_d2h.record(down_stream)
+
+    def collect(self, to_cpu):
+        """The finished batch's embeddings (host copy when to_cpu); frees the slot."""
+        emb = self.out_dev
+        if to_cpu and self.use_cuda and emb.is_cuda:
+            self.ev_d2h.synchronize()
+            emb = self.out_pin[:self.rows * self.dim].view(self.rows, self.dim).clone()
+        elif to_cpu:
+            emb = emb.cpu()
+        self.out_dev = None
+        self.busy = False
+        return emb
+
+
+def predict(model, eval_dataloader, to_cpu=True, device=None):
+    """scripts/encode_corpus.py:126-151 without its per-batch stalls.  The reference moves a batch to the GPU,
+    runs the model and calls `.cpu()` on the result before it touches the next batch.  Here two batches are in
+    flight (the side-stream idea of the reference's own training prefetcher, retrieval/data/pre_dataset.py:28-61):
+    while batch i runs on the compute stream, batch i + 1's token tensors go from pinned host staging to the
+    device on a copy stream and batch i - 1's embeddings go to pinned host memory on a download stream.
+    Row order = dataloader order; a failing batch raises (rows are never dropped)."""
     model.eval()
+    use_cuda = torch.cuda.is_available()
+    if use_cuda:
+        if device is None:
+            idx = getattr(model, "device_index", None)
+            device = torch.device("cuda", torch.cuda.current_device() if idx is None else idx)
+        copy_stream = torch.cuda.Stream(device=device)
+        down_stream = torch.cuda.Stream(device=device)
+        cur = torch.cuda.current_stream(device)
+    else:
+        copy_stream = down_stream = cur = None
+    slots = [_PipeSlot(use_cuda), _PipeSlot(use_cuda)]
     embed_array = []
-    for batch in eval_dataloader:
-        batch = move_to_cuda(batch)
-        embed = model(batch)["embed"]
-        embed_array.append(embed.cpu() if to_cpu else embed)
+    it = iter(eval_dataloader)
+
+    def stage(i):
+        try:
+            batch = next(it)
+        except StopIteration:
+            return None
+        s = slots[i % 2]
+        if s.busy:                       # its previous batch (i - 2) has not been collected yet
+            embed_array.append(s.collect(to_cpu))
+        return s.upload(batch, device, copy_stream)
+
+    i = 0
+    nxt = stage(0)
+    pending = []                         # slots whose embeddings are on their way, oldest first
+    while nxt is not None:
+        s = slots[i % 2]
+        if use_cuda:
+            cur.wait_event(s.ev_h2d)
+        embed = model(nxt)["embed"]
+        s.download(embed, down_stream, to_cpu)
+        pending.append(s)
+        # stage batch i + 1 while batch i computes; its slot holds batch i - 1, collected first
+        if len(pending) == 2:
+            embed_array.append(pending.pop(0).collect(to_cpu))
+        i += 1
+        nxt = stage(i)
+    for s in pending:
+        embed_array.append(s.collect(to_cpu))
     if not embed_array:
         raise ValueError("predict: the dataloader produced no batches")
     return torch.cat(embed_array, dim=0)

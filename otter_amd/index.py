@@ -4,7 +4,8 @@ Mirrors `index = faiss.IndexFlatIP(d); index.add(xb); D, I = index.search(q, k)`
 (reference scripts/eval_ottqa_retrieval.py:108-109,129): same names, same argument
 meaning, same result layout (D float32 [nq, k] descending, I int64 [nq, k], -1 padding).
 numpy in -> numpy out (host copies); torch device tensors in -> torch device tensors
-out (zero copy, work only enqueued on the current stream).
+out (zero copy; work is enqueued on the current stream -- a search of 33 and more queries also
+waits for it once per pass of the coarse search, see include/otter_hip.h).
 
 All compute happens in libotter_hip.so (otter_amd/csrc/index.hip); there is no CPU path.
 """
@@ -89,8 +90,9 @@ class IndexFlatIP:
         _lib.check(self._lib.otter_index_add(self._h, ctypes.c_void_p(x.ctypes.data), x.shape[0], 0,
                                              _stream_ptr(self.device)), "otter_index_add")
 
-    def search(self, q, k):
-        """D, I = index.search(q, k)."""
+    def search(self, q, k, out=None):
+        """D, I = index.search(q, k).  out=(D, I): device queries only -- contiguous float32 / int64 [nq, k]
+        tensors on this index's device that take the result (e.g. views of an exchange buffer)."""
         k = int(k)
         if k < 1 or k > _lib.OTTER_MAX_K:
             raise ValueError("search: k=%d outside [1, %d]" % (k, _lib.OTTER_MAX_K))
@@ -101,12 +103,22 @@ class IndexFlatIP:
                 raise ValueError("search: tensor on %s, index on device %d" % (q.device, self.device))
             q = q.to(torch.float32).contiguous()
             nq = q.shape[0]
-            D = torch.empty((nq, k), dtype=torch.float32, device=q.device)
-            I = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+            if out is not None:
+                D, I = out
+                for t, dt in ((D, torch.float32), (I, torch.int64)):
+                    if not (_is_torch(t) and t.is_cuda and t.device == q.device and t.dtype == dt and
+                            tuple(t.shape) == (nq, k) and t.is_contiguous()):
+                        raise ValueError("search: out must be contiguous (float32, int64) [%d, %d] tensors on %s"
+                                         % (nq, k, q.device))
+            else:
+                D = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+                I = torch.empty((nq, k), dtype=torch.int64, device=q.device)
             _lib.check(self._lib.otter_index_search(self._h, ctypes.c_void_p(q.data_ptr()), nq, k,
                                                     ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()), 1,
                                                     _stream_ptr(self.device)), "otter_index_search")
             return D, I
+        if out is not None:
+            raise ValueError("search: out= is for queries on the index's device")
         if _is_torch(q):
             q = q.detach().numpy()
         q = np.ascontiguousarray(q, dtype=np.float32)
@@ -196,6 +208,12 @@ class IndexFlatIP:
         _lib.check(self._lib.otter_index_reconstruct_n(self._h, int(i0), n, ctypes.c_void_p(out.ctypes.data), 0,
                                                        _stream_ptr(self.device)), "otter_index_reconstruct_n")
         return out
+
+    @property
+    def coarse_state(self):
+        """0: bf16 planes of the coarse pass not built yet, 1: in use, 2: no room in HBM (the exact kernel serves
+        every batch size), 3: not an fp32 index."""
+        return int(self._lib.otter_index_coarse_state(self._h))
 
     @property
     def last_fallback(self):

@@ -4,18 +4,27 @@ torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the
 Replaces the reference's multi-GPU modes:
   * faiss.index_cpu_to_all_gpus (scripts/eval_ottqa_retrieval.py:110-112: replicas of the whole
     index) -> shard g holds rows [g*ceil(N/G), min(N, (g+1)*ceil(N/G))); every rank searches its
-    shard for ALL queries (ids already global via id_base), then ONE all-gather of the
-    (score, id) candidates [nq, k] per rank and a G-way merge on every rank.  When the gathered
-    candidates would be large (config 5: 16,384 queries x top-1000 = 197 MB per rank, 1.57 GB
-    gathered) the exchange is sliced by queries instead: an all-to-all hands rank r every shard's
-    candidates for ITS ceil(nq/G) queries (point-to-point messages, one xGMI link each, no ring),
-    rank r merges them, and one all-gather of the merged [nq/G, k] slices follows.
+    shard for ALL queries (ids already global via id_base), then ONE all-gather of the packed
+    (id, score) candidates -- 12 bytes per candidate, [nq, k] per rank -- and a G-way merge on
+    every rank.  When the gathered candidates would be large (config 5: 16,384 queries x top-1000
+    = 197 MB per rank, 1.57 GB gathered) the exchange is sliced by queries instead: one all-to-all
+    hands rank r every shard's packed candidates for ITS ceil(nq/G) queries (point-to-point
+    messages, one xGMI link each, no ring), rank r merges them, and one all-gather of the merged
+    packed [nq/G, k] slices follows.
   * nn.DataParallel over the encoder (scripts/encode_corpus.py:112-113: weights re-broadcast and
     outputs gathered every step) -> rank r encodes its own contiguous row range with resident
     weights; no data-path collective (one all-gather of row counts at the end).
+
+The collective itself stays in torch.distributed (plumbing: the process group, its RCCL
+communicator and its stream ordering belong to the host program); the C ABI takes and returns
+plain device pointers either side of it (otter_index_search into the send buffer,
+otter_merge_topk out of the receive buffer).
 """
+import numpy as np
 import torch
 import torch.distributed as dist
+
+NEG = -3.4028234663852886e38   # faiss' "missing" score
 
 
 def shard_range(n, world, rank):
@@ -26,28 +35,55 @@ def shard_range(n, world, rank):
     return lo, hi
 
 
+class PackedCandidates:
+    """One exchange buffer for `rows` x k candidates: int64 ids first (8-byte aligned), float32
+    scores behind them -- 12 bytes per candidate, one collective instead of two.  D and I are views:
+    a search that takes output tensors writes straight into the send buffer."""
+
+    def __init__(self, rows, k, device, lead=()):
+        self.rows, self.k = int(rows), int(k)
+        self.nbytes = (self.rows * self.k * 12 + 15) // 16 * 16     # 16-byte multiple: slices of a [G, nbytes] buffer stay aligned
+        self.buf = torch.empty(tuple(lead) + (self.nbytes,), dtype=torch.uint8, device=device)
+
+    def views(self, buf=None):
+        b = self.buf if buf is None else buf
+        cut = self.rows * self.k * 8
+        lead = b.shape[:-1]
+        I = b[..., :cut].view(torch.int64).view(lead + (self.rows, self.k))
+        D = b[..., cut:cut + self.rows * self.k * 4].view(torch.float32).view(lead + (self.rows, self.k))
+        return D, I
+
+
 class ShardedIndexFlatIP:
     """The IndexFlatIP surface over a corpus sharded by rows across the ranks of a process group.
 
     index_factory(d, id_base) -> object with add(x)/search(q, k)/ntotal (default: the HIP index on
     this rank's GPU); merge_fn(Dc, Ic) -> (D, I) merges [G, nq, k] candidates (default: the GPU
-    merge kernel).  Both are injectable so that the collective protocol is testable on CPU."""
+    merge kernel).  Both are injectable so that the collective protocol is testable on CPU.
+    With the default factory queries may be numpy / CPU tensors (results come back as numpy) or
+    tensors on this rank's GPU (results stay there).  `exchange_device`: where the collective's
+    tensors live -- None = where search() returned them (RCCL: the GPU); "cpu" stages them through
+    the host (a gloo group over GPU indexes: bench.py's one-GPU rehearsal)."""
 
     # candidate bytes over all ranks from which the exchange is sliced by queries ("auto")
     SLICED_FROM_BYTES = 64 << 20
 
-    def __init__(self, d, group=None, device=None, index_factory=None, merge_fn=None, exchange="auto"):
+    def __init__(self, d, group=None, device=None, index_factory=None, merge_fn=None, exchange="auto",
+                 exchange_device=None, dtype="fp32"):
         if exchange not in ("auto", "gather", "sliced"):
             raise ValueError("exchange must be 'auto', 'gather' or 'sliced'")
         self.exchange = exchange
+        self.exchange_device = None if exchange_device is None else torch.device(exchange_device)
         self.d = int(d)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = None
         if index_factory is None:
             from .index import IndexFlatIP, merge_topk
             dev = torch.cuda.current_device() if device is None else torch.device(device).index
-            index_factory = lambda dd, base: IndexFlatIP(dd, device=dev, id_base=base)  # noqa: E731
+            self.device = torch.device("cuda", dev)
+            index_factory = lambda dd, base: IndexFlatIP(dd, device=dev, id_base=base, dtype=dtype)  # noqa: E731
             merge_fn = merge_fn or (lambda Dc, Ic: merge_topk(Dc, Ic, device=dev))
         if merge_fn is None:
             raise ValueError("merge_fn is required with a custom index_factory")
@@ -56,6 +92,8 @@ class ShardedIndexFlatIP:
         self.local = None
         self.ntotal = 0
         self.lo = self.hi = 0
+        self.last_exchange = None      # "gather" / "sliced": what the last search() used (tests, bench)
+        self.last_exchange_bytes = 0   # bytes this rank sent in the last search()
 
     def add_global(self, x):
         """Every rank is handed the same [N, d] array (or an object sliceable by rows, e.g. a
@@ -78,64 +116,105 @@ class ShardedIndexFlatIP:
             self.local.add(x_local)
         self.ntotal = int(ntotal)
 
+    def _local_search(self, q, k):
+        """(D, I) torch tensors [nq, k] of this rank's shard, on the device the collective will use."""
+        D, I = self.local.search(q, k)
+        if not torch.is_tensor(D):
+            D, I = torch.from_numpy(np.ascontiguousarray(D)), torch.from_numpy(np.ascontiguousarray(I))
+        if self.exchange_device is not None:
+            D, I = D.to(self.exchange_device), I.to(self.exchange_device)
+        return D, I
+
     def search(self, q, k):
         """D, I = search(q, k) on every rank (same result everywhere)."""
         if self.local is None:
             raise RuntimeError("search before add")
-        D, I = self.local.search(q, k)
+        as_numpy = False
+        if self.device is not None and not (torch.is_tensor(q) and q.is_cuda):
+            # host queries with the HIP index: the exchange runs on device tensors (RCCL), numpy comes back
+            as_numpy = True
+            q = torch.as_tensor(np.ascontiguousarray(q, dtype=np.float32)).to(self.device)
         if self.world == 1:
-            return D, I
+            D, I = self.local.search(q, k)
+        else:
+            nq, kk = int(q.shape[0]), int(k)
+            mode = self.exchange
+            if mode == "auto":
+                mode = "sliced" if self.world * nq * kk * 12 >= self.SLICED_FROM_BYTES else "gather"
+            self.last_exchange = mode
+            if mode == "gather" and self.device is not None and self.exchange_device is None:
+                # the HIP search writes (D, I) straight into the packed send buffer: no pack step
+                send = PackedCandidates(nq, kk, self.device)
+                Ds, Is = send.views()
+                self.local.search(q, kk, out=(Ds, Is))
+                D, I = self._gather_packed(send)
+            else:
+                D, I = self._local_search(q, kk)
+                D, I = self._exchange_sliced(D, I) if mode == "sliced" else self._exchange_gather(D, I)
+            if self.device is not None and D.device != self.device:
+                D, I = D.to(self.device), I.to(self.device)
+        if as_numpy:
+            return D.cpu().numpy(), I.cpu().numpy()
+        return D, I
+
+    def _exchange_gather(self, D, I):
+        """One all-gather of the packed candidates (12 B x nq x k per rank: 2.66 MB at nq = 2214,
+        k = 100), then the G-way merge on every rank."""
+        nq, kk = D.shape
+        send = PackedCandidates(nq, kk, D.device)
+        Ds, Is = send.views()
+        Ds.copy_(D)
+        Is.copy_(I)
+        return self._gather_packed(send)
+
+    def _gather_packed(self, send):
+        G = self.world
+        recv = torch.empty((G * send.nbytes,), dtype=torch.uint8, device=send.buf.device)
+        dist.all_gather_into_tensor(recv, send.buf, group=self.group)
+        self.last_exchange_bytes = send.nbytes
+        Dg, Ig = send.views(recv.view(G, send.nbytes))
+        return self._merged(Dg, Ig)
+
+    def _merged(self, Dg, Ig):
+        dev = Dg.device
+        if self.device is not None and dev != self.device:
+            Dg, Ig = Dg.to(self.device), Ig.to(self.device)
+        D, I = self._merge(Dg.contiguous(), Ig.contiguous())
         if not torch.is_tensor(D):
             D, I = torch.from_numpy(D), torch.from_numpy(I)
-        D = D.contiguous()
-        I = I.contiguous()
+        return D, I
+
+    def _exchange_sliced(self, D, I):
+        """SURVEY.md §8e option B.  Rank r owns queries [r*per, (r+1)*per), per = ceil(nq/G); rows past
+        nq are padding (score -FLT_MAX, id -1: the "missing" convention the merge already handles)."""
+        G = self.world
         nq, kk = D.shape
-        mode = self.exchange
-        if mode == "auto":
-            mode = "sliced" if self.world * nq * kk * 12 >= self.SLICED_FROM_BYTES else "gather"
-        if mode == "sliced":
-            return self._exchange_sliced(D, I)
-        # concatenated along dim 0 (the layout every backend's all_gather_into_tensor accepts)
-        Dg = torch.empty((self.world * nq, kk), dtype=D.dtype, device=D.device)
-        Ig = torch.empty((self.world * nq, kk), dtype=I.dtype, device=I.device)
-        # candidate exchange: 12 B x nq x k per rank (2.66 MB at nq = 2214, k = 100)
-        dist.all_gather_into_tensor(Dg, D, group=self.group)
-        dist.all_gather_into_tensor(Ig, I, group=self.group)
-        return self._merge(Dg.view(self.world, nq, kk), Ig.view(self.world, nq, kk))
-
-
-def _exchange_sliced_impl(self, D, I):
-    """SURVEY.md §8e option B.  Rank r owns queries [r*per, (r+1)*per), per = ceil(nq/G); rows past nq
-    are padding (score -FLT_MAX, id -1: the "missing" convention the merge already handles)."""
-    G = self.world
-    nq, kk = D.shape
-    per = -(-nq // G)
-    pad = per * G
-    if pad != nq:
-        Dp = torch.full((pad, kk), -3.4028234663852886e38, dtype=D.dtype, device=D.device)
-        Ip = torch.full((pad, kk), -1, dtype=I.dtype, device=I.device)
-        Dp[:nq] = D
-        Ip[:nq] = I
-    else:
-        Dp, Ip = D, I
-    # all-to-all with equal splits: chunk r of my rows goes to rank r; I receive chunk `rank` of every rank
-    Dr = torch.empty_like(Dp)
-    Ir = torch.empty_like(Ip)
-    dist.all_to_all_single(Dr, Dp, group=self.group)
-    dist.all_to_all_single(Ir, Ip, group=self.group)
-    Dm, Im = self._merge(Dr.view(G, per, kk), Ir.view(G, per, kk))
-    if not torch.is_tensor(Dm):
-        Dm, Im = torch.from_numpy(Dm), torch.from_numpy(Im)
-    Dm = Dm.to(D.device).contiguous()
-    Im = Im.to(I.device).contiguous()
-    Dg = torch.empty((pad, kk), dtype=D.dtype, device=D.device)
-    Ig = torch.empty((pad, kk), dtype=I.dtype, device=I.device)
-    dist.all_gather_into_tensor(Dg, Dm, group=self.group)
-    dist.all_gather_into_tensor(Ig, Im, group=self.group)
-    return Dg[:nq], Ig[:nq]
-
-
-ShardedIndexFlatIP._exchange_sliced = _exchange_sliced_impl
+        per = -(-nq // G)
+        pad = per * G
+        # chunk r of the send buffer = packed candidates of rank r's queries
+        send = PackedCandidates(per, kk, D.device, lead=(G,))
+        Ds, Is = send.views()
+        for r in range(G):
+            lo, hi = r * per, min(nq, (r + 1) * per)
+            if hi > lo:
+                Ds[r, :hi - lo].copy_(D[lo:hi])
+                Is[r, :hi - lo].copy_(I[lo:hi])
+            if hi - lo < per:
+                Ds[r, max(0, hi - lo):].fill_(NEG)
+                Is[r, max(0, hi - lo):].fill_(-1)
+        recv = torch.empty_like(send.buf)
+        dist.all_to_all_single(recv.view(-1), send.buf.view(-1), group=self.group)
+        Dr, Ir = send.views(recv)                              # [G, per, kk]: every shard's list of MY queries
+        Dm, Im = self._merged(Dr, Ir)
+        mine = PackedCandidates(per, kk, D.device)
+        Dv, Iv = mine.views()
+        Dv.copy_(Dm.to(D.device))
+        Iv.copy_(Im.to(I.device))
+        allb = torch.empty((G * mine.nbytes,), dtype=torch.uint8, device=D.device)
+        dist.all_gather_into_tensor(allb, mine.buf, group=self.group)
+        self.last_exchange_bytes = send.buf.numel() + mine.nbytes
+        Dg, Ig = mine.views(allb.view(G, mine.nbytes))         # [G, per, kk] in query order
+        return Dg.reshape(pad, kk)[:nq].contiguous(), Ig.reshape(pad, kk)[:nq].contiguous()
 
 
 def encode_rows(model, batches, n_rows, group=None, to_cpu=False):

@@ -123,3 +123,49 @@ def test_collate_and_predict_never_drop_rows():
             predict(Boom(), [b])
     finally:
         drv.move_to_cuda = old
+
+
+def test_predict_pipeline_keeps_order_and_row_counts():
+    """Two batches in flight, slots reused: ragged batch sizes and sequence lengths, every row accounted for
+    in dataloader order (the host logic of the pipelined predict(); the stream overlap runs on the GPU box)."""
+    class Model:
+        def __init__(self):
+            self.seen = []
+
+        def eval(self):
+            return self
+
+        def __call__(self, batch):
+            ids = batch["input_ids"]
+            self.seen.append(tuple(ids.shape))
+            # embedding = (first token id, sum of the mask) per row
+            return {"embed": torch.stack([ids[:, 0].float(), batch["input_mask"].sum(1).float()], dim=1)}
+
+    batches = []
+    row = 0
+    for bs, L in [(4, 7), (4, 3), (1, 9), (3, 9), (2, 1)]:
+        ids = torch.arange(row, row + bs).view(-1, 1).repeat(1, L)
+        mask = torch.ones((bs, L), dtype=torch.int32)      # a non-int64 tensor is converted, not rejected
+        batches.append({"input_ids": ids, "input_mask": mask})
+        row += bs
+    m = Model()
+    emb = predict(m, iter(batches))
+    assert emb.shape == (row, 2)
+    assert torch.equal(emb[:, 0], torch.arange(row).float())
+    assert emb[:, 1].tolist() == [7.0] * 4 + [3.0] * 4 + [9.0] * 4 + [1.0] * 2
+    assert m.seen == [(4, 7), (4, 3), (1, 9), (3, 9), (2, 1)]
+    with pytest.raises(ValueError):
+        predict(m, iter([]))
+
+
+def test_sharded_search_with_numpy_queries_and_a_numpy_index():
+    """a factory whose search returns numpy (as the HIP index does for host queries) must work
+    at world > 1 -- single process here, world 1 falls through; the packing helpers are checked directly."""
+    pc = sharded.PackedCandidates(3, 5, "cpu")
+    D, I = pc.views()
+    D.copy_(torch.arange(15, dtype=torch.float32).view(3, 5))
+    I.copy_(torch.arange(15, dtype=torch.int64).view(3, 5) * 7)
+    two = torch.cat([pc.buf, pc.buf]).view(2, pc.nbytes)
+    D2, I2 = pc.views(two)
+    assert D2.shape == (2, 3, 5) and torch.equal(D2[1], D) and torch.equal(I2[0], I)
+    assert pc.nbytes % 16 == 0 and pc.nbytes >= 15 * 12
