@@ -88,6 +88,22 @@ int otter_index_add(otter_index* ix, const void* x, int64_t n, int x_is_device, 
 int otter_index_search(otter_index* ix, const void* q, int64_t nq, int k,
                        float* D, int64_t* I, int io_is_device, void* stream);
 
+/* otter_index_search for callers that cannot allocate.  NO counterpart in the reference: it exists for callers
+ * that cannot call hipMalloc -- code under HIP graph capture, tight serving loops (the reference's real call
+ * pattern is one query per call, scripts/eval_ottqa_retrieval.py:126-129), harnesses that forbid allocation.
+ * Same kernels and bit-identical results as otter_index_search; every byte of device scratch (padded queries,
+ * per-strip candidate lists and counts, sample list and thresholds, merge levels) lives in ONE static 25 MiB
+ * __device__ array per GPU that is part of the library's code object (each GPU the library runs on holds its
+ * copy until the process ends).  The call issues no hipMalloc / hipFree and no allocating library routine, and
+ * only enqueues work on `stream`.
+ * Limits (OTTER_EINVAL beyond them): OTTER_F32 index, 0 <= nq <= 32, 1 <= k <= 128, d <= 4096; q, D, I are
+ * device pointers (float32 [nq, d], float32 [nq, k], int64 [nq, k]).  The measurement hook
+ * (otter_index_set_timing) does not cover this entry point.
+ * All calls on one GPU share that GPU's array: two calls that overlap in time on the same GPU (different
+ * streams or threads, any index) race; calls on one stream are ordered and safe. */
+int otter_index_search_noalloc(otter_index* ix, const float* q, int64_t nq, int k,
+                               float* D, int64_t* I, void* stream);
+
 /* index.ntotal / index.d */
 /* Search restricted to per-query row subsets.  Replaces the reference's per-question throw-away index
  * (retrieval/eval_ottqa_retrieval_tfidffilter.py:530-546: faiss.IndexFlatIP(d); index.add(qid2emb[qid]);

@@ -42,6 +42,7 @@ SIGNATURES = {
     "otter_index_create": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_vp)]),
     "otter_index_add": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
     "otter_index_search": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_vp]),
+    "otter_index_search_noalloc": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
     "otter_index_ntotal": (c_i64, [c_vp]),
     "otter_index_d": (c_int, [c_vp]),
     "otter_index_reset": (c_int, [c_vp]),

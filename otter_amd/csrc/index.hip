@@ -1451,9 +1451,28 @@ struct otter_index {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
 };
 
-constexpr int NA_MAX_STRIPS = 256;
+// Scratch of otter_index_search_noalloc (include/otter_hip.h): one fixed region per GPU, part of the code
+// object, so the entry point never allocates.  Layout = the bump allocation order of search_chunk() for the
+// largest shape that entry point accepts (32 queries, k <= 128, d <= 4096, 256 strips):
+//   qpad 32 x 4096 x 4 | cand 256 x 32 x 384 x 8 | cnt | sample list, count, threshold | merge level lists
+constexpr int NA_MAX_NQ = 32, NA_MAX_K = 128, NA_MAX_LD = 4096, NA_MAX_STRIPS = 256;
+constexpr size_t NA_SCRATCH_BYTES = 25ull << 20;      // 25 MiB (the layout above needs 24.8 MiB)
+static __device__ __align__(256) unsigned char scratch[NA_SCRATCH_BYTES];
 
 namespace {
+
+// device address of `scratch` on each GPU (the array's name is a host-side stand-in, not a device address)
+unsigned char* g_scratch_ptr[64] = {};
+
+int resolve_scratch(int device) {
+    if (device < 0 || device >= 64) return set_err(OTTER_EINVAL, "device %d outside [0, 64)", device);
+    if (g_scratch_ptr[device]) return OTTER_OK;
+    void* p = nullptr;
+    OTTER_HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));     // the device is current (DeviceGuard of the caller)
+    if (!p) return set_err(OTTER_EHIP, "hipGetSymbolAddress(scratch) returned NULL on device %d", device);
+    g_scratch_ptr[device] = (unsigned char*)p;
+    return OTTER_OK;
+}
 
 // Where a search's device scratch comes from: the index's grow-only buffers (may call hipMalloc), or a fixed
 // region handed out by a bump pointer (never allocates; running out is an error).
@@ -2105,6 +2124,13 @@ int otter_index_create(int d, int dtype, int device, otter_index** out) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return set_err(OTTER_ESTATE, "index_create: device %d is %s; this library is built for gfx950 only", device,
                        prop.gcnArchName);
+    {
+        // set-up of otter_index_search_noalloc: this device's address of the static scratch array, once per device
+        DeviceGuard g(device);
+        if (!g.ok) return set_err(OTTER_EHIP, "index_create: hipSetDevice(%d) failed", device);
+        const int rs = resolve_scratch(device);
+        if (rs) return rs;
+    }
     otter_index* ix = new (std::nothrow) otter_index();
     if (!ix) return set_err(OTTER_ENOMEM, "index_create: host allocation failed");
     ix->d = d;
@@ -2209,6 +2235,33 @@ int otter_index_search(otter_index* ix, const void* q, int64_t nq, int k, float*
         OTTER_HIP_TRY(hipStreamSynchronize(st));
     }
     return OTTER_OK;
+}
+
+// otter_index_search for callers that cannot allocate: same kernels, scratch in the static per-GPU array.
+int otter_index_search_noalloc(otter_index* ix, const float* q, int64_t nq, int k, float* D, int64_t* I, void* stream) {
+    if (!ix) return set_err(OTTER_EINVAL, "search_noalloc: index is NULL");
+    if (ix->dtype != OTTER_F32) return set_err(OTTER_ENOTIMPL, "search_noalloc: OTTER_F32 indexes only");
+    if (nq < 0 || nq > NA_MAX_NQ)
+        return set_err(OTTER_EINVAL, "search_noalloc: nq=%lld outside [0, %d] (use otter_index_search)", (long long)nq, NA_MAX_NQ);
+    if (k < 1 || k > NA_MAX_K) return set_err(OTTER_EINVAL, "search_noalloc: k=%d outside [1, %d] (use otter_index_search)", k, NA_MAX_K);
+    if (ix->ld > NA_MAX_LD) return set_err(OTTER_EINVAL, "search_noalloc: d=%d exceeds %d (use otter_index_search)", ix->d, NA_MAX_LD);
+    if (nq == 0) return OTTER_OK;
+    if (!q || !D || !I) return set_err(OTTER_EINVAL, "search_noalloc: q, D and I must be non-NULL device pointers");
+    DeviceGuard g(ix->device);
+    if (!g.ok) return set_err(OTTER_EHIP, "search_noalloc: hipSetDevice(%d) failed", ix->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (ix->n == 0) {
+        const long long total = (long long)nq * k;
+        hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, st,
+                           D, (long long*)I, total);
+        OTTER_HIP_TRY(hipGetLastError());
+        return OTTER_OK;
+    }
+    Scratch sc;
+    sc.fixed = g_scratch_ptr[ix->device];       // resolved by otter_index_create on this device
+    sc.fixed_bytes = NA_SCRATCH_BYTES;
+    if (!sc.fixed) return set_err(OTTER_ESTATE, "search_noalloc: static scratch of device %d was not resolved", ix->device);
+    return search_chunk(ix, q, nq, k, D, (long long*)I, st, &sc);
 }
 
 // Search restricted to per-query id subsets: the reference builds a throw-away

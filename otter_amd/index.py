@@ -132,6 +132,20 @@ class IndexFlatIP:
                                                 _stream_ptr(self.device)), "otter_index_search")
         return D, I
 
+    def search_noalloc(self, q, k, D, I):
+        """otter_index_search_noalloc: at most 32 queries, k <= 128, fp32 index; q, D, I are caller-owned tensors
+        on this index's device (float32 [nq, d], float32 [nq, k], int64 [nq, k], contiguous).  The library call
+        allocates nothing (its scratch is a static per-GPU array); work is only enqueued on the current stream."""
+        for t, dt, shape in ((q, torch.float32, (q.shape[0], self.d)), (D, torch.float32, (q.shape[0], int(k))),
+                             (I, torch.int64, (q.shape[0], int(k)))):
+            if not (_is_torch(t) and t.is_cuda and t.device.index == self.device and t.dtype == dt and
+                    tuple(t.shape) == shape and t.is_contiguous()):
+                raise ValueError("search_noalloc: expected a contiguous %s %r tensor on device %d" % (dt, shape, self.device))
+        _lib.check(self._lib.otter_index_search_noalloc(self._h, ctypes.c_void_p(q.data_ptr()), q.shape[0], int(k),
+                                                        ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()),
+                                                        _stream_ptr(self.device)), "otter_index_search_noalloc")
+        return D, I
+
     def search_subsets(self, q, k, subsets, return_positions=False):
         """Per-query search restricted to row subsets: what the reference does by building a throw-away
         faiss.IndexFlatIP over each question's TF-IDF-filtered blocks
