@@ -530,7 +530,7 @@ def main():
 
     enc = None
     if not args.no_encode:
-        enc = encode_leg(rank, world, local_rank, dist, max(4, args.steps // 2), min(3, max(1, args.warmup)),
+        enc = encode_leg(rank, world, local_rank, dist, max(8, args.steps), min(3, max(1, args.warmup)),
                          args.encode_batch, world == 1 and not args.no_cpu_baseline, rehearse)
 
     if rank == 0:

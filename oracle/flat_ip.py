@@ -237,3 +237,35 @@ def check_topk(xb, q, D, I, k, rtol=1e-5, id_base=0):
         assert (s64[iq] >= kth - 2 * tol[iq]).all(), "query %d returned a row outside the top-%d" % (iq, k)
         ndiff += int((order != Iv[iq]).sum())
     return ndiff
+
+
+def check_against_golden(g, D, I, k):
+    """The comparison rule of SURVEY.md §8c against a committed fixture of oracle/gen_search_goldens.py
+    (g: the loaded npz).  With tol = 1e-5 * |q| * max|x|:
+      * position by position, the returned id must be a row of the float64 top-(k+8) whose float64 score is
+        within tol of the score the float64 ranking has at that position (ids may differ from the float64
+        ranking only inside runs of scores closer than the tolerance);
+      * |D - float64 score of the returned row| <= tol; D non-increasing; ids unique;
+      * rows the corpus does not have: I = -1, D = -FLT_MAX.
+    Returns the number of positions whose id differs from the float64 ranking."""
+    Ig, s64, ids64 = g["I"].astype(np.int64), g["s64"], g["ids64"].astype(np.int64)
+    nq = Ig.shape[0]
+    assert D.shape == (nq, k) and I.shape == (nq, k) and D.dtype == np.float32 and I.dtype == np.int64
+    tol = 1e-5 * g["qnorm"] * float(g["xmax"]) + 1e-30
+    ndiff = 0
+    for iq in range(nq):
+        nvalid = int((Ig[iq] >= 0).sum())
+        assert (I[iq, nvalid:] == -1).all() and (D[iq, nvalid:] == NEG).all(), "padding of query %d" % iq
+        got = I[iq, :nvalid]
+        assert len(set(got.tolist())) == nvalid, "duplicate ids in query %d" % iq
+        assert (D[iq, 1:nvalid] <= D[iq, :nvalid - 1]).all(), "query %d not sorted" % iq
+        score_of = {int(i): float(s) for i, s in zip(ids64[iq], s64[iq]) if i >= 0}
+        for p in range(nvalid):
+            gid = int(got[p])
+            assert gid in score_of, "query %d position %d: row %d is not in the float64 top-(k+8)" % (iq, p, gid)
+            sg = score_of[gid]
+            assert abs(sg - s64[iq, p]) <= 2 * tol[iq], "query %d position %d: row %d ranks elsewhere (%g vs %g)" % (
+                iq, p, gid, sg, s64[iq, p])
+            assert abs(float(D[iq, p]) - sg) <= tol[iq], "query %d position %d: score %g, float64 %g" % (iq, p, D[iq, p], sg)
+            ndiff += int(gid != Ig[iq, p])
+    return ndiff

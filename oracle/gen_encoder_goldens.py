@@ -70,33 +70,49 @@ def _hf_model_dir(cfg, sd, tmp, tag):
 ONLY = [t for t in os.environ.get("OTTER_GOLDEN_ONLY", "").split(",") if t]   # regenerate just these tags
 
 
-def run_case(tag, cfg, wseed, batch, tmp, klass="threecat", encode_table=True, probes=None, dup_b1=False):
+def run_case(tag, cfg, wseed, batch, tmp, klass="threecat", encode_table=True, probes=None, dup_b1=False, q_seed=None):
+    """klass: 'threecat' / 'onevec' / 'ctx' (the ...CtxEncoder classes).  q_seed: shared_encoder=False with a second,
+    different set of encoder weights under 'encoder_q.*' in the checkpoint (tb_retriever.py:160-161,205-218)."""
     if ONLY and tag not in ONLY:
         return
-    from retrieval.models.retriever import RobertaSingleEncoder, SingleEncoder
+    from retrieval.models.retriever import CtxEncoder, RobertaCtxEncoder, RobertaSingleEncoder, SingleEncoder
     from retrieval.models.tb_retriever import RobertaSingleEncoderThreeCatPool, SingleEncoderThreeCatPool
     from retrieval.models.tb_retriever import RobertaSingleEncoderThreeCatAtt, SingleEncoderThreeCatAtt
     from retrieval.utils.utils import load_saved
     sd = R.make_state_dict(cfg, wseed)
     mdir, hcfg = _hf_model_dir(cfg, sd, tmp, tag)
-    args = SimpleNamespace(model_name=mdir, shared_encoder=True, no_proj=cfg["no_proj"],
-                           part_pooling=cfg["part_pooling"], encode_table=encode_table)
+    args = SimpleNamespace(model_name=mdir, shared_encoder=q_seed is None, no_proj=cfg["no_proj"],
+                           part_pooling=cfg["part_pooling"], encode_table=encode_table, multi_vector=1, scheme="none")
     rob = cfg["family"] == "roberta"
+    ck_sd = dict(sd)
+    sd_used = sd                      # the weights the forward under test actually runs on
+    if q_seed is not None:
+        sdq = R.make_state_dict(cfg, q_seed)
+        for k, v in sdq.items():
+            if k.startswith("encoder."):
+                ck_sd["encoder_q." + k[len("encoder."):]] = v
+        if not encode_table:
+            sd_used = dict(sd)
+            sd_used.update({k: v for k, v in sdq.items() if k.startswith("encoder.")})
+    if klass == "ctx" and not rob:    # CtxEncoder names its HF model `encoder_c`
+        ck_sd = {("encoder_c." + k[len("encoder."):] if k.startswith("encoder.") else k): v for k, v in ck_sd.items()}
     if klass == "threecat" and str(cfg["part_pooling"])[:3] == "att":
         model = (RobertaSingleEncoderThreeCatAtt if rob else SingleEncoderThreeCatAtt)(hcfg, args)
     elif klass == "threecat":
         model = (RobertaSingleEncoderThreeCatPool if rob else SingleEncoderThreeCatPool)(hcfg, args)
+    elif klass == "ctx":
+        model = (RobertaCtxEncoder if rob else CtxEncoder)(hcfg, args)
     else:
         model = (RobertaSingleEncoder if rob else SingleEncoder)(hcfg, args)
     ck = os.path.join(tmp, tag + ".pt")
-    torch.save({"module." + k: v for k, v in sd.items()}, ck)      # DataParallel-style prefix: load_saved strips it
+    torch.save({"module." + k: v for k, v in ck_sd.items()}, ck)   # DataParallel-style prefix: load_saved strips it
     model = load_saved(model, ck, exact=False)
     model.eval()
     run_batch = batch
     if dup_b1:   # the reference cannot run B=1 with 'first' pooling (tb_retriever.py:55 squeezes the batch dim)
         run_batch = {k: torch.cat([v, v], 0) for k, v in batch.items()}
     with torch.no_grad():
-        if rob:
+        if rob or klass == "ctx":
             out = model(run_batch)["embed"]
         else:
             # SingleEncoder*.forward reads self.encode_table, which only the Roberta subclasses set
@@ -115,7 +131,7 @@ def run_case(tag, cfg, wseed, batch, tmp, klass="threecat", encode_table=True, p
         out = out[:1]
     out = out.float().numpy()
     # the restatement that travels must reproduce the reference here
-    mine = R.EncoderRef(cfg, sd)(batch)["embed"].numpy()
+    mine = R.EncoderRef(cfg, sd_used)(batch)["embed"].numpy()
     err = float(np.abs(mine - out).max())
     scale = float(np.abs(out).max())
     print("%-34s embed %-12s max|ref| %.3f  max|restatement - reference| %.3g" % (tag, out.shape, scale, err))
@@ -123,6 +139,9 @@ def run_case(tag, cfg, wseed, batch, tmp, klass="threecat", encode_table=True, p
     save = {k: v.numpy() for k, v in batch.items()}
     save["expected_embed"] = out
     save["weight_seed"] = np.int64(wseed)
+    save["q_weight_seed"] = np.int64(-1 if q_seed is None else q_seed)
+    save["klass"] = np.asarray(klass)
+    save["encode_table"] = np.int64(1 if encode_table else 0)
     if probes is not None:
         layers, pos = probes
         save["probe_layers"] = np.asarray(layers, dtype=np.int64)
@@ -187,6 +206,16 @@ def main():
                  probes=([0, 1, 6, 12], [0, 1, 100]))
         run_case("rob12_question_L70", cfg, 99, R.make_batch(cfg, 3, 70, 778, question=True), tmp,
                  encode_table=False)
+        # the corpus-side one-vector classes of retrieval/models/retriever.py:513-564
+        cfg = R.make_config("roberta", three_cat=False, no_proj=False, **small)
+        run_case("rob2_ctx", cfg, 17, R.make_batch(cfg, 4, 96, 30), tmp, klass="ctx")
+        cfg = R.make_config("bert", layers=2, vocab_size=2000, three_cat=False, no_proj=True)
+        run_case("bert2_ctx", cfg, 18, R.make_batch(cfg, 3, 80, 31), tmp, klass="ctx")
+        # shared_encoder=False: questions run on encoder_q.* (different weights), blocks on encoder.*
+        cfg = R.make_config("roberta", **small)
+        run_case("rob2_question_notshared", cfg, 11, R.make_batch(cfg, 5, 70, 23, question=True), tmp,
+                 encode_table=False, q_seed=19)
+        run_case("rob2_first_notshared", cfg, 11, R.make_batch(cfg, 4, 96, 21), tmp, q_seed=19)
 
 
 if __name__ == "__main__":

@@ -100,6 +100,9 @@ class _PipeSlot:
         return emb
 
 
+_PIPE_CACHE = {}
+
+
 def predict(model, eval_dataloader, to_cpu=True, device=None):
     """scripts/encode_corpus.py:126-151 without its per-batch stalls.  The reference moves a batch to the GPU,
     runs the model and calls `.cpu()` on the result before it touches the next batch.  Here two batches are in
@@ -113,12 +116,16 @@ def predict(model, eval_dataloader, to_cpu=True, device=None):
         if device is None:
             idx = getattr(model, "device_index", None)
             device = torch.device("cuda", torch.cuda.current_device() if idx is None else idx)
-        copy_stream = torch.cuda.Stream(device=device)
-        down_stream = torch.cuda.Stream(device=device)
+        device = torch.device(device)
+        # streams and pinned staging are kept per device between calls (pinned allocations cost milliseconds)
+        if device not in _PIPE_CACHE:
+            _PIPE_CACHE[device] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device),
+                                   [_PipeSlot(True), _PipeSlot(True)])
+        copy_stream, down_stream, slots = _PIPE_CACHE[device]
         cur = torch.cuda.current_stream(device)
     else:
         copy_stream = down_stream = cur = None
-    slots = [_PipeSlot(use_cuda), _PipeSlot(use_cuda)]
+        slots = [_PipeSlot(False), _PipeSlot(False)]
     embed_array = []
     it = iter(eval_dataloader)
 

@@ -78,12 +78,14 @@ class _EncoderBase:
     three_cat = True
     roberta = False
     att = False            # ...ThreeCatAtt: attention pooling with its own self_proj_tab / self_proj_psg tensors
+    enc_prefix = "encoder"  # attribute name of the HF model in the reference class = its state_dict key prefix
+    force_no_proj = None   # the ...CtxEncoder classes fix the projection instead of reading args.no_proj
 
     def __init__(self, config, args, device=None, dtype=None):
         self.config = config
         self.args = args
         self.shared_encoder = bool(getattr(args, "shared_encoder", True))
-        self.no_proj = bool(getattr(args, "no_proj", True))
+        self.no_proj = bool(getattr(args, "no_proj", True)) if self.force_no_proj is None else self.force_no_proj
         self.part_pooling = getattr(args, "part_pooling", "first") if self.three_cat else "cls"
         self.encode_table = bool(getattr(args, "encode_table", True))
         if self.part_pooling[:3] == "att" and not (self.att and self.part_pooling == "att_self_pool"):
@@ -134,7 +136,7 @@ class _EncoderBase:
         return keys
 
     def state_dict_keys(self):
-        keys = ["encoder." + k for k in self._expected_keys()]
+        keys = [self.enc_prefix + "." + k for k in self._expected_keys()]
         if not self.shared_encoder:
             keys += ["encoder_q." + k for k in self._expected_keys()]
         keys += ["project.0.weight", "project.0.bias", "project.1.weight", "project.1.bias"]
@@ -144,9 +146,9 @@ class _EncoderBase:
 
     def state_dict(self):
         out = OrderedDict()
-        for grp in ("encoder", "encoder_q"):
+        for grp, prefix in (("encoder", self.enc_prefix), ("encoder_q", "encoder_q")):
             for k, v in self._weights[grp].items():
-                out[grp + "." + k] = v
+                out[prefix + "." + k] = v
         for k, v in self._weights["project"].items():
             out[k] = v
         return out
@@ -163,8 +165,8 @@ class _EncoderBase:
             t = v.detach().to(torch.float32).cpu().contiguous()
             if k.startswith("encoder_q."):
                 self._weights["encoder_q"][k[len("encoder_q."):]] = t
-            elif k.startswith("encoder."):
-                self._weights["encoder"][k[len("encoder."):]] = t
+            elif k.startswith(self.enc_prefix + "."):
+                self._weights["encoder"][k[len(self.enc_prefix) + 1:]] = t
             else:
                 self._weights["project"][k] = t
         loaded = set(self.state_dict().keys())
@@ -342,3 +344,31 @@ class SingleEncoder(_EncoderBase):
 class RobertaSingleEncoder(_EncoderBase):
     """retrieval/models/retriever.py:334-345."""
     three_cat, roberta = False, True
+
+
+class RobertaCtxEncoder(_EncoderBase):
+    """retrieval/models/retriever.py:547-564: one vector, the projection head always on
+    (`project(encoder(ids, mask)[0][:, 0, :])`), whatever args.no_proj says."""
+    three_cat, roberta, force_no_proj = False, True, False
+
+    def forward(self, batch):
+        return {"embed": self.encode_seq(batch["input_ids"], batch["input_mask"])}
+
+    __call__ = forward
+
+
+class CtxEncoder(_EncoderBase):
+    """retrieval/models/retriever.py:513-544 (BERT family): the HF model is the attribute `encoder_c`
+    (state_dict keys 'encoder_c.*'), no projection, embed = h[:, 0].  Only args.multi_vector <= 1 is built: the
+    reference's multi-vector branches read `self.encoder`, an attribute that class never sets."""
+    three_cat, roberta, force_no_proj, enc_prefix = False, False, True, "encoder_c"
+
+    def __init__(self, config, args, device=None, dtype=None):
+        if int(getattr(args, "multi_vector", 1) or 1) > 1:
+            raise NotImplementedError("CtxEncoder: multi_vector > 1 reads self.encoder, which the reference class does not define")
+        super().__init__(config, args, device=device, dtype=dtype)
+
+    def forward(self, batch):
+        return {"embed": self.encode_seq(batch["input_ids"], batch["input_mask"], batch.get("input_type_ids"))}
+
+    __call__ = forward

@@ -32,6 +32,29 @@ def load_golden(name):
     return cfg, int(z["weight_seed"]), batch, z["expected_embed"], extra
 
 
+def golden_meta(name):
+    """(klass, q_weight_seed or None, encode_table) of a fixture; older fixtures carry the convention in their name."""
+    z = np.load(os.path.join(GOLD, "encoder_%s.npz" % name), allow_pickle=False)
+    if "klass" in z.files:
+        qs = int(z["q_weight_seed"])
+        return str(z["klass"]), (None if qs < 0 else qs), bool(int(z["encode_table"]))
+    return None, None, "question" not in name
+
+
+def weights_for(cfg, seed, q_seed=None, encode_table=True):
+    """(checkpoint-style state_dict incl. encoder_q.* when q_seed is given, the weights the tested forward runs on)."""
+    sd = state_dict_for(cfg, seed)
+    if q_seed is None:
+        return sd, sd
+    sdq = R.make_state_dict(cfg, q_seed)
+    ck = dict(sd)
+    ck.update({"encoder_q." + k[len("encoder."):]: v for k, v in sdq.items() if k.startswith("encoder.")})
+    used = dict(sd)
+    if not encode_table:
+        used.update({k: v for k, v in sdq.items() if k.startswith("encoder.")})
+    return ck, used
+
+
 _SD_CACHE = {}
 
 
@@ -49,6 +72,7 @@ def hf_like_config(cfg):
                                                   "pad_token_id", "layer_norm_eps")})
 
 
-def ref_args(cfg, encode_table=True, fp16=False):
-    return SimpleNamespace(model_name="unused", shared_encoder=True, no_proj=bool(cfg["no_proj"]),
-                           part_pooling=str(cfg["part_pooling"]), encode_table=encode_table, fp16=fp16)
+def ref_args(cfg, encode_table=True, fp16=False, shared_encoder=True):
+    return SimpleNamespace(model_name="unused", shared_encoder=shared_encoder, no_proj=bool(cfg["no_proj"]),
+                           part_pooling=str(cfg["part_pooling"]), encode_table=encode_table, fp16=fp16,
+                           multi_vector=1, scheme="none")

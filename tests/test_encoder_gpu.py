@@ -17,9 +17,25 @@ pytestmark = pytest.mark.gpu
 CLASSES = {}
 
 
-def _model(cfg, seed, dtype="fp32", encode_table=True):
+def _model(cfg, seed, dtype="fp32", encode_table=True, klass=None, q_seed=None):
     from otter_amd import encoder as E
     att = cfg["three_cat"] and str(cfg["part_pooling"])[:3] == "att"
+    if klass == "ctx":
+        # CtxEncoder keeps its HF model under `encoder_c`: hand it a checkpoint with the reference's key names
+        rob = cfg["family"] == "roberta"
+        sd = U.state_dict_for(cfg, seed)
+        if not rob:
+            sd = {("encoder_c." + k[len("encoder."):] if k.startswith("encoder.") else k): v for k, v in sd.items()}
+        m = (E.RobertaCtxEncoder if rob else E.CtxEncoder)(U.hf_like_config(cfg), U.ref_args(cfg), dtype=dtype)
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not missing, missing
+        return m.to("cuda:0").eval()
+    if q_seed is not None:
+        cls = E.RobertaSingleEncoderThreeCatPool if cfg["family"] == "roberta" else E.SingleEncoderThreeCatPool
+        m = cls(U.hf_like_config(cfg), U.ref_args(cfg, encode_table=encode_table, shared_encoder=False), dtype=dtype)
+        missing, unexpected = m.load_state_dict(U.weights_for(cfg, seed, q_seed, encode_table)[0], strict=False)
+        assert not missing and not unexpected, (missing, unexpected)
+        return m.to("cuda:0").eval()
     if cfg["family"] == "roberta":
         cls = (E.RobertaSingleEncoderThreeCatAtt if att else E.RobertaSingleEncoderThreeCatPool) if cfg["three_cat"] \
             else E.RobertaSingleEncoder
@@ -40,7 +56,8 @@ def _close(got, exp, rtol=1e-4, atol=1e-4):
 @pytest.mark.parametrize("name", U.golden_names())
 def test_fp32_forward_matches_reference_fixture(name):
     cfg, seed, batch, expected, extra = U.load_golden(name)
-    model = _model(cfg, seed, encode_table="question" not in name)
+    klass, q_seed, encode_table = U.golden_meta(name)
+    model = _model(cfg, seed, encode_table=encode_table, klass=klass, q_seed=q_seed)
     out = model({k: v.cuda() for k, v in batch.items()})["embed"]
     assert out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == expected.shape
     got = out.cpu().numpy()
@@ -91,6 +108,18 @@ def test_load_saved_and_module_prefix(tmp_path):
     model = E.load_saved(model, str(ck), exact=False)
     got = model(E.move_to_cuda(batch))["embed"].cpu().numpy()
     _close(got, expected)
+
+
+def test_ctx_encoder_surface():
+    from types import SimpleNamespace
+    from otter_amd import encoder as E
+    cfg, _, _, _, _ = U.load_golden("bert2_ctx")
+    with pytest.raises(NotImplementedError):
+        E.CtxEncoder(U.hf_like_config(cfg), SimpleNamespace(multi_vector=3, scheme="tokenwise"))
+    m = E.CtxEncoder(U.hf_like_config(cfg), SimpleNamespace(multi_vector=1, scheme="none"))
+    assert all(k.startswith(("encoder_c.", "project.")) for k in m.state_dict_keys())
+    r = E.RobertaCtxEncoder(U.hf_like_config(cfg), SimpleNamespace(no_proj=True))
+    assert r.no_proj is False          # the projection head of RobertaCtxEncoder is not optional
 
 
 def test_errors_are_loud():

@@ -11,7 +11,8 @@ from tests import _enc_util as U
 @pytest.mark.parametrize("name", U.golden_names())
 def test_restatement_matches_reference_fixture(name):
     cfg, seed, batch, expected, extra = U.load_golden(name)
-    ref = R.EncoderRef(cfg, U.state_dict_for(cfg, seed))
+    klass, q_seed, encode_table = U.golden_meta(name)
+    ref = R.EncoderRef(cfg, U.weights_for(cfg, seed, q_seed, encode_table)[1])
     got = ref(batch)["embed"].numpy()
     assert got.shape == expected.shape
     scale = max(1.0, float(np.abs(expected).max()))
