@@ -30,6 +30,7 @@ namespace {
 using namespace otter;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 typedef uint32_t u32;
 
@@ -79,6 +80,20 @@ __device__ __forceinline__ void dma16s(const void* sbase, u32 voff, u32 lds_dst)
         : "v"(voff), "s"(sbase), "s"(lds_dst)
         : "memory");
 }
+// the corpus stream of the exact kernels: every byte is read once per search, so the loads carry the non-temporal
+// policy (measured on the stream kernel, 1 query x 1M x 768: 0.536 -> 0.482 ms; SCAN_NO_NT builds without it)
+__device__ __forceinline__ void dma16s_stream(const void* sbase, u32 voff, u32 lds_dst) {
+#ifndef SCAN_NO_NT
+    u32 keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+#else
+    dma16s(sbase, voff, lds_dst);
+#endif
+}
 // workgroup barrier that does NOT drain the vector-memory queue (LDS-DMA stays in flight)
 __device__ __forceinline__ void wg_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -100,6 +115,8 @@ struct ScanArgs {
     int tile_begin;     // first tile (rows below tile_begin * BM belong to the sample pass)
     const u32* thr0;    // [nq_pad] initial score-key threshold per query (null: none)
     int order;          // 0: strip fastest within an XCD's range, 1: query tile fastest (speed only)
+    int q_rows;         // rows that exist behind Q (nq_pad for a padded copy; nq when the caller's rows are read in place)
+    int skip_final;     // 1: leave the strip's candidates uncompacted (<= CAP per query: one-tile strips); the merge selects
     u64* dbg;           // SCAN_DIAG builds only: per-wave cycle sums {total, stage wait, epilogue, stages}
 };
 
@@ -261,7 +278,13 @@ __global__ __launch_bounds__(WM * WQ * 64, WM * WQ / 4) void scan_kernel(ScanArg
     for (int t = 0; t < IPS; ++t) {
         const int i = (t < A_INSTR ? t : t - A_INSTR) * NW + wave;
         const int r = RPI * i + dma_r;
-        voff[t] = ((u32)r * (u32)a.ld + (u32)((dma_p ^ swz(r)) << 2)) * 4u;
+        // query side: a row past the batch reads the batch's last row instead (its scores are never accepted)
+        const int rs = t < A_INSTR ? r : min(r, max(a.q_rows - 1 - q0, 0));
+        voff[t] = ((u32)rs * (u32)a.ld + (u32)((dma_p ^ swz(r)) << 2)) * 4u;
+#ifdef SCAN_ABL_BLOCKED
+        // timing-only ablation: read every stage of the corpus as ONE contiguous block (results are garbage)
+        if (t < A_INSTR) voff[t] = ((u32)r * (u32)BK + (u32)((dma_p ^ swz(r)) << 2)) * 4u;
+#endif
     }
     const float* gQ = a.Q + (size_t)q0 * a.ld;
 
@@ -275,7 +298,11 @@ __global__ __launch_bounds__(WM * WQ * 64, WM * WQ / 4) void scan_kernel(ScanArg
     auto produce_begin = [&](int slot) {
         pr_have = it_tile < t1;
         if (pr_have) {
+#ifdef SCAN_ABL_BLOCKED
+            pr_gA = a.X + ((size_t)it_tile * BM * a.ld + (size_t)it_ks * BK * BM);
+#else
             pr_gA = a.X + ((size_t)it_tile * BM * a.ld + (size_t)it_ks * BK);
+#endif
             pr_gB = gQ + (size_t)it_ks * BK;
             pr_lds = lds0 + slot * STAGE_BYTES;
             if (++it_ks == KS) { it_ks = 0; ++it_tile; }
@@ -287,7 +314,7 @@ __global__ __launch_bounds__(WM * WQ * 64, WM * WQ / 4) void scan_kernel(ScanArg
 #else
         if (pr_have) {
 #endif
-            if (t < A_INSTR) dma16s(pr_gA, voff[t], pr_lds + (t * NW + wave) * 1024);
+            if (t < A_INSTR) dma16s_stream(pr_gA, voff[t], pr_lds + (t * NW + wave) * 1024);
             else dma16s(pr_gB, voff[t], pr_lds + A_BYTES + ((t - A_INSTR) * NW + wave) * 1024);
         }
     };
@@ -387,6 +414,13 @@ __global__ __launch_bounds__(WM * WQ * 64, WM * WQ / 4) void scan_kernel(ScanArg
                 for (int m = 0; m < MB; ++m)
 #pragma unroll
                     for (int q = 0; q < QB; ++q) {
+#ifdef SCAN_ABL_NOMFMA
+                        // timing-only ablation: the fragments are read, one product instead of four (results are garbage)
+                        asm volatile("" ::"v"(af[cb][m].x), "v"(af[cb][m].y), "v"(af[cb][m].z), "v"(af[cb][m].w), "v"(bf[cb][q].x),
+                                     "v"(bf[cb][q].y), "v"(bf[cb][q].z), "v"(bf[cb][q].w));
+                        if (j == 0) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][m].x, bf[cb][q].x, acc[m][q], 0, 0, 0);
+                        continue;
+#endif
                         acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][m].x, bf[cb][q].x, acc[m][q], 0, 0, 0);
                         acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][m].y, bf[cb][q].y, acc[m][q], 0, 0, 0);
                         acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][m].z, bf[cb][q].z, acc[m][q], 0, 0, 0);
@@ -447,8 +481,327 @@ __global__ __launch_bounds__(WM * WQ * 64, WM * WQ / 4) void scan_kernel(ScanArg
     }
 #endif
     // ---- end of strip: leave at most k composites per query, publish counts ----
+    if (a.skip_final) {
+        wait_vmcnt<0>();
+        wg_barrier();
+    } else {
+        compact_pass(true);
+    }
+    for (int i = tid; i < BQ; i += NT) a.cnt[(size_t)strip * a.nq_pad + q0 + i] = min(sCnt[i], (u32)CAP);
+}
+
+// ------------------------------------------------------------------ stream kernel (at most 32 queries)
+// The reference's real call pattern is ONE query per search() call (scripts/eval_ottqa_retrieval.py:126-129):
+// N*d*4 bytes per call, HBM-bound up to about 32 queries.  A 32x32x2 MFMA computes 32 query columns whatever nq
+// is (55 % of a stage's time at 1 query), so this regime has a kernel of its own:
+//   lane = corpus row.  A wave owns 64 consecutive rows of a 256-row tile and streams ITS OWN rows through
+//   its own LDS ring (slots of [8 KiB rows | the queries' 32 floats], LDS-DMA with the non-temporal policy --
+//   every corpus byte is read once per search --, counted vmcnt): no workgroup barrier in the main loop.
+//   Scores: v_mfma_f32_4x4x1_16b_f32 -- 16 blocks of (4 rows) x (4 queries) x (ONE k) per instruction, i.e. a
+//   plain fma per output and instruction, issued in scan_kernel's k order (0,4,1,5,2,6,3,7 per 8): bit-identical
+//   to the 32x32x2 kernels and to the oracle's fmaf chain.  G = ceil(nq / 4) instructions per k: the matrix-core
+//   time scales with nq (1/8 of the 32x32x2 tile's at <= 4 queries).
+//   No sample pass: after its FIRST tile every wave publishes, per query, the best of its 64 rows (a composite);
+//   the workgroup that arrives last selects each query's k-th best of these <= 1024 block maxima -- a valid lower
+//   bound of the k-th best score, since it is the k-th best of a subset of rows -- and publishes it; the other
+//   workgroups hold the scores of their first tiles in registers until the thresholds are there (polled at tile
+//   boundaries, never waited for: after ST_HOLD held tiles a workgroup falls back to learning its own threshold).
+//   Hand-offs follow MI355X_MICROARCH.md "Valid forms": sc1 stores, every storing wave's vmcnt(0), workgroup
+//   barrier, one agent-scope atomic add per workgroup; consumers poll with an sc1 load and read the payload with
+//   sc1 loads.  Acceptance is key >= threshold (rows of other strips may tie it).
+struct StreamArgs {
+    const float* X;      // [n][ld]
+    const float* Q;      // [q_rows][ld]
+    u64* cand;           // [S][4 G][CAP]
+    u32* cnt;            // [S][4 G]
+    long long n;
+    int ld, nq, k;
+    int strips;          // workgroups
+    int total_tiles;     // 256-row tiles
+    int q_rows;          // rows that exist behind Q
+    int seed;            // 1: threshold exchange on
+    u64* bmax;           // [4 G][4 * strips] block maxima of every wave's first tile
+    u32* sync;           // [0] arrivals, [1] ready, [2..33] thresholds (keys); zero at launch, zeroed again by the merge
+};
+
+constexpr int ST_BM = 256, ST_HOLD = 3, ST_SYNC_WORDS = 34;
+constexpr int st_qinstr(int G, int BK) { return (4 * G * BK * 4 + 1023) / 1024; }              // LDS-DMA instructions for the queries
+constexpr int st_slot(int G, int BK) { return 64 * BK * 4 + st_qinstr(G, BK) * 1024; }        // per wave and stage
+constexpr int st_ips(int G, int BK) { return BK / 4 + st_qinstr(G, BK); }                     // LDS-DMA instructions per wave and stage
+
+// k-th largest of the n <= 64 * EPL composites in x (unique, zero = empty): radix select by ballots
+template <int EPL>
+__device__ __forceinline__ u64 wave_kth(const u64 (&x)[EPL], int k) {
+    u64 T = 0ull;
+    for (int b = 63; b >= 0; --b) {
+        const u64 c = T | (1ull << b);
+        int cntv = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) cntv += __popcll(__ballot(x[e] >= c));
+        if (cntv >= k) T = c;
+        if (cntv == k) {
+            // exactly k composites are >= c: the k-th largest is their minimum
+            u64 mn = ~0ull;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) mn = (x[e] >= c && x[e] < mn) ? x[e] : mn;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const u64 v = __shfl_xor(mn, o);
+                mn = v < mn ? v : mn;
+            }
+            return mn;
+        }
+    }
+    return T;
+}
+
+template <int G, int EPL, int ST_BK, int ST_NSTAGE>
+__global__ __launch_bounds__(256) void stream_kernel(StreamArgs a) {
+    constexpr int NQP = 4 * G;                 // query columns computed (padded to whole 4x4 blocks)
+    constexpr int CAP = EPL * 64;
+    constexpr int QI = st_qinstr(G, ST_BK), ST_SLOT = st_slot(G, ST_BK), ST_IPS = st_ips(G, ST_BK);
+    constexpr int CH = ST_BK / 4;              // 16-byte chunks per row of a stage
+    constexpr int RPI = 64 / CH;               // rows per LDS-DMA instruction
+    constexpr int ROWB = ST_BK * 4;            // bytes per row of a stage
+    static_assert(ST_BK == 32 || ST_BK == 64, "stage depth");
+    static_assert(CAP - ST_BM >= 128, "candidate buffer too small");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32* sCnt = reinterpret_cast<u32*>(smem + 4 * ST_NSTAGE * ST_SLOT);
+    u32* sThr = sCnt + 32;
+    u32* sFlag = sThr + 32;       // [0] compaction wanted, [1] thresholds ready, [2] this workgroup selects
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int strip = blockIdx.x;
+    const int t0 = (int)(((long long)strip * a.total_tiles) / a.strips);
+    const int t1 = (int)(((long long)(strip + 1) * a.total_tiles) / a.strips);
+    const int KS = a.ld / ST_BK;
+    if (tid < 32) {
+        sCnt[tid] = 0;
+        sThr[tid] = 0u;            // accept everything (key >= 0) until a threshold is known
+    }
+    if (tid < 3) sFlag[tid] = 0;
+    u64* candBase = a.cand + (size_t)strip * NQP * CAP;
+
+    // ---- producer: this wave's 64 rows x BK floats (1 KiB per instruction) + the queries' BK floats
+    // LDS image: [row][CH chunks of 16 B], chunk position p of row r holds global chunk p ^ swz(r), swz chosen so
+    // that the rows one ds_read_b128 lane group touches fall on distinct 16-byte slots of the 256-byte bank row
+    auto swz = [](int r) { return CH == 16 ? (r & 15) : ((r >> 1) & 7); };
+    const u32 lds0 = (u32)(uintptr_t)(AS3 char*)smem + (u32)wave * (ST_NSTAGE * ST_SLOT);
+    u32 voffA[CH], voffQ[QI];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int r = RPI * i + lane / CH;
+        voffA[i] = ((u32)(wave * 64 + r) * (u32)a.ld + (u32)(((lane % CH) ^ swz(r)) << 2)) * 4u;
+    }
+#pragma unroll
+    for (int i = 0; i < QI; ++i) {
+        const int r = RPI * i + lane / CH;       // a row past the batch reads its last row (never accepted)
+        voffQ[i] = ((u32)min(r, max(a.q_rows - 1, 0)) * (u32)a.ld + (u32)((lane % CH) << 2)) * 4u;
+    }
+    const long long total_stages = (long long)(t1 - t0) * KS;
+    int it_tile = t0, it_ks = 0;
+    long long it_f = 0;
+    auto issue_stage = [&]() {
+        if (it_f < total_stages) {
+            const float* gA = a.X + ((size_t)it_tile * ST_BM * a.ld + (size_t)it_ks * ST_BK);
+            const float* gQ = a.Q + (size_t)it_ks * ST_BK;
+            const u32 l = lds0 + (u32)(it_f % ST_NSTAGE) * ST_SLOT;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) dma16s_stream(gA, voffA[i], l + i * 1024);
+#pragma unroll
+            for (int i = 0; i < QI; ++i) dma16s(gQ, voffQ[i], l + CH * 1024 + i * 1024);
+            ++it_f;
+            if (++it_ks == KS) { it_ks = 0; ++it_tile; }
+        }
+    };
+
+    // ---- candidate path.  Lane l holds, per query group g, the scores of rows 4 (l >> 2) + i (i = 0..3) of this
+    // wave's 64 for query 4 g + (l & 3)
+    const int rsub = wave * 64 + 4 * (lane >> 2);
+    auto append_tile = [&](const f32x4 (&sc)[G], int tile) {
+        const long long row0 = (long long)tile * ST_BM + rsub;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int q = 4 * g + (lane & 3);
+            const u32 thr = sThr[q];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32 key = f2key(sc[g][i]);
+                if (q < a.nq && key >= thr && row0 + i < a.n) {
+                    const u32 pos = atomicAdd(&sCnt[q], 1u);
+                    if (pos < (u32)CAP)
+                        candBase[(u32)q * (u32)CAP + pos] = ((u64)key << 32) | (u64)(0xFFFFFFFFu - (u32)(row0 + i));
+                    if (pos + 1 > (u32)(CAP - ST_BM)) sFlag[0] = 1;
+                }
+            }
+        }
+    };
+    auto compact_pass = [&](bool final_pass) {      // workgroup-wide; every wave calls it at the same point
+        wait_vmcnt<0>();
+        wg_barrier();
+        for (int q = wave; q < NQP; q += 4) {
+            const int n = (int)min(sCnt[q], (u32)CAP);
+            const bool need = final_pass ? (n > a.k) : (n > CAP - ST_BM);
+            if (need) {
+                const u64 T = wave_compact<EPL>(candBase + (size_t)q * CAP, n, a.k, lane);
+                if (lane == 0) {
+                    sCnt[q] = (u32)a.k;
+                    sThr[q] = max(sThr[q], (u32)(T >> 32));
+                }
+            }
+        }
+        if (tid == 0) sFlag[0] = 0;
+        wait_vmcnt<0>();
+        wg_barrier();
+    };
+
+    f32x4 acc[G];
+    f32x4 held[ST_HOLD][G];
+    int nheld = 0, held_tile0 = t0;
+    bool have_thr = a.seed == 0;     // no exchange: thresholds are learned locally from the start
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s2 = 0; s2 < ST_NSTAGE - 1; ++s2) issue_stage();
+
+    const u32 rowoff = (u32)lane * (u32)ROWB;
+    const u32 rswz = (u32)swz(lane);
+    const u32 qoff = (u32)(lane & 3) * (u32)ROWB;
+    long long f = 0;
+    for (int tile = t0; tile < t1; ++tile) {
+        for (int ks = 0; ks < KS; ++ks, ++f) {
+            // stage f (this wave's own loads) has landed once at most NSTAGE-2 younger stages are outstanding
+            if (total_stages - 1 - f >= ST_NSTAGE - 2) wait_vmcnt<(ST_NSTAGE - 2) * ST_IPS>();
+            else wait_vmcnt<0>();
+            // the slot of stage f-1 was read by this wave only, and those reads have returned (their values fed
+            // the products above): refill it with stage f + NSTAGE - 1
+            wait_lgkm0();
+            issue_stage();
+            const char* sA = smem + wave * (ST_NSTAGE * ST_SLOT) + (int)(f % ST_NSTAGE) * ST_SLOT;
+            const char* sQ = sA + CH * 1024;
+#pragma unroll
+            for (int j = 0; j < ST_BK / 8; ++j) {
+                const float4 x0 = *reinterpret_cast<const float4*>(sA + rowoff + (((u32)(2 * j) ^ rswz) << 4));
+                const float4 x1 = *reinterpret_cast<const float4*>(sA + rowoff + (((u32)(2 * j + 1) ^ rswz) << 4));
+                // lanes l, l + 4, ... read the same query row: four addresses per instruction
+                float4 q0[G], q1[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    q0[g] = *reinterpret_cast<const float4*>(sQ + g * 4 * ROWB + qoff + (2 * j) * 16);
+                    q1[g] = *reinterpret_cast<const float4*>(sQ + g * 4 * ROWB + qoff + (2 * j + 1) * 16);
+                }
+                // one k per instruction, the G query groups interleaved (independent accumulators back to back)
+#define ST_STEP(XA, QA)                                                                              \
+    _Pragma("unroll") for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(XA, QA, acc[g], 0, 0, 0);
+                ST_STEP(x0.x, q0[g].x)
+                ST_STEP(x1.x, q1[g].x)
+                ST_STEP(x0.y, q0[g].y)
+                ST_STEP(x1.y, q1[g].y)
+                ST_STEP(x0.z, q0[g].z)
+                ST_STEP(x1.z, q1[g].z)
+                ST_STEP(x0.w, q0[g].w)
+                ST_STEP(x1.w, q1[g].w)
+#undef ST_STEP
+            }
+        }
+        // ---- end of a tile
+        if (have_thr) {
+            append_tile(acc, tile);
+        } else {
+            if (nheld == 0) held_tile0 = tile;
+#pragma unroll
+            for (int h = 0; h < ST_HOLD; ++h)
+                if (h == nheld)
+#pragma unroll
+                    for (int g = 0; g < G; ++g) held[h][g] = acc[g];
+            ++nheld;
+        }
+        if (a.seed && tile == t0) {
+            // publish the best row of this wave's first tile, per query (composites; 0 = no valid row)
+            const long long row0 = (long long)tile * ST_BM + rsub;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int q = 4 * g + (lane & 3);
+                u64 c = 0ull;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u64 v = (q < a.nq && row0 + i < a.n)
+                                      ? (((u64)f2key(acc[g][i]) << 32) | (u64)(0xFFFFFFFFu - (u32)(row0 + i))) : 0ull;
+                    c = v > c ? v : c;
+                }
+#pragma unroll
+                for (int o = 32; o >= 4; o >>= 1) {      // over the lanes that hold this query
+                    const u64 v = __shfl_xor(c, o);
+                    c = v > c ? v : c;
+                }
+                if (lane < 4 && q < a.nq)
+                    __hip_atomic_store(a.bmax + (size_t)q * (4 * a.strips) + 4 * strip + wave, c, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+            wait_vmcnt<0>();            // this wave's stores have left (once per launch: the ring drains with them)
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        wg_barrier();                   // tile boundary: every wave has appended / published
+        if (a.seed && tile == t0) {
+            if (tid == 0) {
+                const u32 old = __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sFlag[2] = (old == (u32)a.strips - 1u) ? 1u : 0u;
+            }
+            wg_barrier();
+            if (sFlag[2]) {
+                // last arrival: every block maximum is published.  Wave w selects for queries w, w + 4, ...
+                const int M = 4 * a.strips;          // <= 1024 (host)
+                for (int q = wave; q < a.nq; q += 4) {
+                    u64 x[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int idx = e * 64 + lane;
+                        x[e] = idx < M ? __hip_atomic_load(a.bmax + (size_t)q * M + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                       : 0ull;
+                    }
+                    int valid = 0;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) valid += __popcll(__ballot(x[e] != 0ull));
+                    const u64 T = valid >= a.k ? wave_kth<16>(x, a.k) : 0ull;
+                    if (lane == 0)
+                        __hip_atomic_store(a.sync + 2 + q, (u32)(T >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                wait_vmcnt<0>();
+                wg_barrier();
+                if (tid == 0) __hip_atomic_store(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (!have_thr) {
+            // thresholds there yet?  (one sc1 poll per tile boundary; nobody waits)
+            if (wave == 0) {
+                const u32 r = __hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (r && lane < a.nq)
+                    sThr[lane] = __hip_atomic_load(a.sync + 2 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) sFlag[1] = r;
+            }
+            wg_barrier();
+            const bool ready = sFlag[1] != 0u;
+            if (ready || nheld == ST_HOLD || tile + 1 == t1) {
+                // flush the held tiles through the filter (without thresholds: one tile at a time, compacting)
+#pragma unroll
+                for (int h = 0; h < ST_HOLD; ++h) {
+                    if (h < nheld) {
+                        append_tile(held[h], held_tile0 + h);
+                        wg_barrier();
+                        if (__builtin_amdgcn_readfirstlane(sFlag[0])) compact_pass(false);
+                    }
+                }
+                nheld = 0;
+                have_thr = true;
+            }
+        } else if (__builtin_amdgcn_readfirstlane(sFlag[0])) {
+            compact_pass(false);
+        }
+    }
     compact_pass(true);
-    for (int i = tid; i < BQ; i += NT) a.cnt[(size_t)strip * a.nq_pad + q0 + i] = sCnt[i];
+    if (tid < NQP) a.cnt[(size_t)strip * NQP + tid] = min(sCnt[tid], (u32)CAP);
 }
 
 // ------------------------------------------------------------------ bf16-MFMA scan
@@ -468,7 +821,6 @@ __global__ __launch_bounds__(WM * WQ * 64, WM * WQ / 4) void scan_kernel(ScanArg
 // the queries on the GEMM's token side (lanes) and the corpus rows on its feature side
 // (accumulator rows), streamed over a strip of corpus tiles, and scan_kernel's epilogue
 // (per-query threshold in LDS, candidate buffers, wave radix compaction).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct Scan16Args {
@@ -1071,148 +1423,264 @@ __global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict
 struct MergeArgs {
     const u64* in;       // [S_in][nq_pad][cap_in]
     const u32* in_cnt;   // [S_in][nq_pad]
-    u64* out;            // [S_out][nq_pad][k]       (intermediate levels)
-    u32* out_cnt;        // [S_out][nq_pad]
+    u64* out;            // [nq_pad][k]  unsorted list of the survivors (non-final)
+    u32* out_cnt;        // [nq_pad]
     float* D;            // [nq][k]                   (final level)
     long long* I;        // [nq][k]
     long long id_base;
     int cap_in;
     int S_in;
-    int fan;             // strips merged by one workgroup
     int nq_pad;
     int k;
-    int npad;            // power of two >= fan * min(cap_in, k) (+ k with an extra list)
     int final_level;
     int take;            // entries gathered from each strip list (k; more only for uncompacted one-tile strips)
     const u64* ex;       // last level only: one more sorted list [nq_pad][k] (the sample passes so far), or null;
                          // may alias `out` (a workgroup has gathered its query's lists before it writes)
     const u32* ex_cnt;   // [nq_pad]
-    u32* thr_out;        // non-final level with one group: [nq_pad] key of the k-th best, 0 if fewer than k
+    u32* thr_out;        // non-final: [nq_pad] key of the k-th best, 0 if fewer than k
+    u32* zero_words;     // the stream kernel's arrival counter, ready flag and thresholds (ST_SYNC_WORDS), left zero; or null
 };
 
-constexpr int MAX_SELECT = 8192;       // composites one merge workgroup selects from in LDS
-constexpr int MERGE_THREADS = 1024;
-constexpr int MERGE_MAX_STRIPS = 1024;   // strips one merge workgroup gathers (host keeps fan below it)
+constexpr int MAX_SELECT = 8192;       // composites one merge workgroup holds in LDS
+constexpr int MERGE_MAX_STRIPS = 256;    // strip counts one merge workgroup scans at a time
 
-__device__ __forceinline__ void bitonic_desc_u64(u64* l, int n, int tid, int nthreads) {
-    for (int size = 2; size <= n; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int i = tid; i < (n >> 1); i += nthreads) {
-                const int lo = 2 * i - (i & (stride - 1));
-                const int hi = lo + stride;
-                const bool desc = (lo & size) == 0;
-                const u64 x = l[lo], y = l[hi];
-                if ((x < y) == desc) { l[lo] = y; l[hi] = x; }
-            }
-        }
-    }
-    __syncthreads();
-}
-
-// One workgroup merges the candidate lists of up to `fan` strips of one query: counts are read
-// in parallel and prefix-summed in LDS (no chain of dependent global loads), one wave copies one
-// strip at a time, and only the live power-of-two prefix is sorted.
-__global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(MergeArgs a) {
+// ---- merge: one workgroup per query, ONE launch for any number of strips ----
+// The strips' candidate lists are gathered into an LDS pool of CAPL composites; whenever the next strips
+// would not fit, the pool is cut back to its k largest (select) and the gather goes on.  With seeded
+// thresholds the lists are short and one round takes everything.
+//   select    distribution select on the 64-bit composites (unique, non-zero): min / max of the live range,
+//             256 bins over it (LDS atomics), the bin that holds the k-th largest becomes the next range
+//             (256x narrower each pass); a range that holds <= 256 candidates is finished by rank counting.
+//   output    final level: the <= k survivors are ordered by rank counting (every survivor counts the
+//             survivors above it: k LDS broadcast reads, no barrier) and written as (D, I);
+//             otherwise the unsorted list, its count and the key of the k-th best (thr_out) are left for a
+//             later merge -- nothing downstream needs an intermediate list ordered.
+template <int NT, int CAPL>
+__global__ __launch_bounds__(NT) void merge_kernel(MergeArgs a) {
+    constexpr int EPT = CAPL / NT;
+    constexpr int NWV = NT / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    u64* l = reinterpret_cast<u64*>(smem);
-    int* sOff = reinterpret_cast<int*>(smem + (size_t)a.npad * sizeof(u64));   // [ns + 2]
+    u64* l = reinterpret_cast<u64*>(smem);                                   // [CAPL]
+    u64* tmp = l + CAPL;                                                     // [256] candidates of the last range
+    int* sOff = reinterpret_cast<int*>(tmp + 256);                           // [MERGE_MAX_STRIPS + 2]
+    u32* hist = reinterpret_cast<u32*>(sOff + MERGE_MAX_STRIPS + 2);         // [256]
+    u64* sRed = reinterpret_cast<u64*>(hist + 256);                          // [2 * NWV] per-wave min / max
+    u64* sT = sRed + 2 * NWV;                                                // [1] selected threshold
+    int* sI = reinterpret_cast<int*>(sT + 1);                                // [8] bin, above, m, position counters
     const int q = blockIdx.x;
-    const int g = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s0 = g * a.fan;
-    const int ns = min(a.S_in, s0 + a.fan) - s0;
-    const bool extra = a.ex != nullptr;
-    for (int t = tid; t < ns + (extra ? 1 : 0); t += MERGE_THREADS) {
-        const int c = t < ns ? (int)a.in_cnt[(size_t)(s0 + t) * a.nq_pad + q] : (int)a.ex_cnt[q];
-        sOff[t + 1] = min(c, t < ns ? a.take : a.k);
-    }
-    __syncthreads();
-    if (wave == 0) {   // inclusive scan of <= MERGE_MAX_STRIPS + 1 counts by one wave
-        int run = 0;
-        const int n = ns + (extra ? 1 : 0);
-        for (int c0 = 0; c0 < n; c0 += 64) {
-            int v = c0 + lane < n ? sOff[c0 + lane + 1] : 0;
+    const int k = a.k;
+
+    // cut the pool l[0, n) back to its k largest (n > k), compacted into l[0, k); returns their minimum
+    auto select = [&](int n) -> u64 {
+        u64 x[EPT];
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int u = __shfl_up(v, o);
-                if (lane >= o) v += u;
-            }
-            if (c0 + lane < n) sOff[c0 + lane + 1] = run + v;
-            run += __shfl(v, 63);
+        for (int e = 0; e < EPT; ++e) {
+            const int idx = e * NT + tid;
+            x[e] = idx < n ? l[idx] : 0ull;
         }
-        if (lane == 0) sOff[0] = 0;
-    }
-    __syncthreads();
-    const int nlist = ns + (extra ? 1 : 0);
-    const int off = sOff[nlist];
-    for (int t = wave; t < nlist; t += MERGE_THREADS / 64) {
-        const int o0 = sOff[t], c = sOff[t + 1] - o0;
-        const u64* src = t < ns ? a.in + ((size_t)(s0 + t) * a.nq_pad + q) * a.cap_in : a.ex + (size_t)q * a.k;
-        for (int i = lane; i < c; i += 64) l[o0 + i] = src[i];
-    }
-    __syncthreads();
-    // Block-wide radix select of the k largest (composites are unique and non-zero): every thread
-    // keeps its <= MAX_SELECT / MERGE_THREADS elements in registers, one ballot count per bit,
-    // stop as soon as exactly k remain; only the survivors are sorted.
-    constexpr int EPT = MAX_SELECT / MERGE_THREADS;
-    u64 x[EPT];
+        // live range [lo, hi] of the composites that still compete; `need` of them are to be kept
+        u64 mn = ~0ull, mx = 0ull;
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int idx = e * MERGE_THREADS + tid;
-        x[e] = idx < off ? l[idx] : 0ull;
-    }
-    u64 T = 1ull;                               // off <= k: keep every gathered composite
-    int* sW = sOff + MERGE_MAX_STRIPS + 4;      // [2][16] per-wave counts, double buffered by round
-    int* sPos = sW + 32;
-    if (off > a.k) {
-        T = 0ull;
-        int par = 0;
-        for (int b = 63; b >= 0; --b, par ^= 1) {
-            const u64 c = T | (1ull << b);
-            int cw = 0;
+        for (int e = 0; e < EPT; ++e)
+            if (x[e]) { mn = x[e] < mn ? x[e] : mn; mx = x[e] > mx ? x[e] : mx; }
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) cw += __popcll(__ballot(x[e] >= c));
-            if (lane == 0) sW[par * 16 + wave] = cw;
+        for (int o = 32; o > 0; o >>= 1) {
+            const u64 a2 = __shfl_xor(mn, o), b2 = __shfl_xor(mx, o);
+            mn = a2 < mn ? a2 : mn;
+            mx = b2 > mx ? b2 : mx;
+        }
+        if (lane == 0) { sRed[wave] = mn; sRed[NWV + wave] = mx; }
+        __syncthreads();
+        u64 lo = sRed[0], hi = sRed[NWV];
+#pragma unroll
+        for (int w = 1; w < NWV; ++w) {
+            lo = sRed[w] < lo ? sRed[w] : lo;
+            hi = sRed[NWV + w] > hi ? sRed[NWV + w] : hi;
+        }
+        int need = k;
+        u64 T = lo;
+        for (int pass = 0; pass < 16; ++pass) {         // (64 bits / 8 bits per pass = 8 passes at most)
+            const u64 range = hi - lo;
+            const int bits = range ? 64 - __builtin_clzll(range) : 0;
+            const int shift = bits > 8 ? bits - 8 : 0;
+            if (tid < 256) hist[tid] = 0u;
+            if (tid == 0) sI[3] = 0;
             __syncthreads();
-            int cntv = 0;
 #pragma unroll
-            for (int w = 0; w < MERGE_THREADS / 64; ++w) cntv += sW[par * 16 + w];
-            if (cntv >= a.k) T = c;
-            if (cntv == a.k) break;             // uniform: every thread sees the same counts
+            for (int e = 0; e < EPT; ++e)
+                if (x[e] >= lo && x[e] <= hi) atomicAdd(&hist[(u32)((x[e] - lo) >> shift)], 1u);
+            __syncthreads();
+            if (wave == 0) {
+                // suffix sums over 256 bins, 4 per lane: the bin B with  sum(bins > B) < need <= sum(bins >= B)
+                const u32 h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+                u32 own = h0 + h1 + h2 + h3, suf = own;       // inclusive suffix over lanes
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const u32 u = __shfl_down(suf, o);
+                    if (lane + o < 64) suf += u;
+                }
+                const u32 after = suf - own;                   // candidates in the bins of higher lanes
+                if (after < (u32)need && suf >= (u32)need) {   // exactly one lane
+                    u32 ab = after;
+                    int B = 4 * lane + 3;
+                    u32 m = h3;
+                    if (ab + h3 >= (u32)need) { B = 4 * lane + 3; m = h3; }
+                    else if (ab + h3 + h2 >= (u32)need) { ab += h3; B = 4 * lane + 2; m = h2; }
+                    else if (ab + h3 + h2 + h1 >= (u32)need) { ab += h3 + h2; B = 4 * lane + 1; m = h1; }
+                    else { ab += h3 + h2 + h1; B = 4 * lane; m = h0; }
+                    sI[0] = B;
+                    sI[1] = (int)ab;
+                    sI[2] = (int)m;
+                }
+            }
+            __syncthreads();
+            const int B = sI[0], above = sI[1], m = sI[2];
+            const u64 nlo = lo + ((u64)B << shift);
+            const u64 nhi = shift ? nlo + ((1ull << shift) - 1ull) : nlo;
+            lo = nlo;
+            hi = nhi < hi ? nhi : hi;
+            need -= above;
+            if (m == need) { T = lo; break; }                  // the whole bin is kept
+            if (m <= 256) {
+                // finish by rank counting among the bin's candidates
+#pragma unroll
+                for (int e = 0; e < EPT; ++e)
+                    if (x[e] >= lo && x[e] <= hi) tmp[atomicAdd(&sI[3], 1)] = x[e];
+                __syncthreads();
+                if (tid < m) {
+                    const u64 v = tmp[tid];
+                    int r = 0;        // (equal composites -- a caller's repeated ids -- rank by position)
+                    for (int j = 0; j < m; ++j) r += (tmp[j] > v) || (tmp[j] == v && j < tid);
+                    if (r == need - 1) *sT = v;
+                }
+                __syncthreads();
+                T = *sT;
+                break;
+            }
+        }
+        // keep the k largest, compacted to the front of the pool: everything above T, then composites equal
+        // to T up to k in all (composites are unique except for a caller's repeated ids)
+        if (tid == 0) sI[4] = 0;
+        __syncthreads();                                       // (every thread holds its elements: l may be overwritten)
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const bool keep = x[e] > T;
+            const u64 mk = __ballot(keep);
+            int base = 0;
+            if (lane == 0 && mk) base = atomicAdd(&sI[4], __popcll(mk));
+            base = __shfl(base, 0);
+            if (keep) l[base + __builtin_amdgcn_mbcnt_hi((u32)(mk >> 32), __builtin_amdgcn_mbcnt_lo((u32)mk, 0))] = x[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const bool keep = x[e] == T;
+            const u64 mk = __ballot(keep);
+            int base = 0;
+            if (lane == 0 && mk) base = atomicAdd(&sI[4], __popcll(mk));
+            base = __shfl(base, 0);
+            const int pos = base + __builtin_amdgcn_mbcnt_hi((u32)(mk >> 32), __builtin_amdgcn_mbcnt_lo((u32)mk, 0));
+            if (keep && pos < k) l[pos] = x[e];
+        }
+        __syncthreads();
+        return T;
+    };
+
+    int n = 0;
+    u64 Tmin = 0ull;             // minimum of the pool when it was last cut to k (0: never cut)
+    if (a.ex) {
+        n = min((int)a.ex_cnt[q], k);
+        const u64* src = a.ex + (size_t)q * k;
+        for (int i = tid; i < n; i += NT) l[i] = src[i];
+    }
+    for (int s0 = 0; s0 < a.S_in; s0 += MERGE_MAX_STRIPS) {
+        const int ns = min(MERGE_MAX_STRIPS, a.S_in - s0);
+        __syncthreads();
+        for (int t = tid; t < ns; t += NT) sOff[t + 1] = min((int)a.in_cnt[(size_t)(s0 + t) * a.nq_pad + q], a.take);
+        __syncthreads();
+        if (wave == 0) {   // inclusive scan of <= MERGE_MAX_STRIPS counts by one wave
+            int run = 0;
+            for (int c0 = 0; c0 < ns; c0 += 64) {
+                int v = c0 + lane < ns ? sOff[c0 + lane + 1] : 0;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int u = __shfl_up(v, o);
+                    if (lane >= o) v += u;
+                }
+                if (c0 + lane < ns) sOff[c0 + lane + 1] = run + v;
+                run += __shfl(v, 63);
+            }
+            if (lane == 0) sOff[0] = 0;
+        }
+        __syncthreads();
+        int sb = 0;
+        while (sb < ns) {
+            // the strips [sb, se) that fit beside the n composites already in the pool (a strip holds <= take
+            // <= CAPL - k entries and n <= k after a cut: at least one strip fits)
+            const int room = CAPL - n + sOff[sb];
+            int se = sb + 1;
+            {
+                int lo2 = sb + 1, hi2 = ns;                    // largest se with sOff[se] <= room
+                while (lo2 < hi2) {
+                    const int mid = (lo2 + hi2 + 1) >> 1;
+                    if (sOff[mid] <= room) lo2 = mid; else hi2 = mid - 1;
+                }
+                se = lo2;
+            }
+            for (int t = sb + wave; t < se; t += NWV) {
+                const int o0 = sOff[t], c = sOff[t + 1] - o0;
+                const u64* src = a.in + ((size_t)(s0 + t) * a.nq_pad + q) * a.cap_in;
+                u64* dst = l + n + (o0 - sOff[sb]);
+                for (int i = lane; i < c; i += 64) dst[i] = src[i];
+            }
+            n += sOff[se] - sOff[sb];
+            sb = se;
+            __syncthreads();
+            const bool more = sb < ns || s0 + MERGE_MAX_STRIPS < a.S_in;
+            if (more && n > k) { Tmin = select(n); n = k; }
         }
     }
-    if (tid == 0) *sPos = 0;
-    __syncthreads();                            // every thread holds its elements: l may be overwritten
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const bool keep = x[e] >= T && x[e] != 0ull;
-        const u64 m = __ballot(keep);
-        int base = 0;
-        if (lane == 0 && m) base = atomicAdd(sPos, __popcll(m));
-        base = __shfl(base, 0);
-        if (keep) l[base + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0))] = x[e];
-    }
     __syncthreads();
-    const int kept = *sPos;                     // == min(off, k)
-    int npad = 2;
-    while (npad < kept) npad <<= 1;             // <= next_pow2(k) <= a.npad
-    for (int i = kept + tid; i < npad; i += MERGE_THREADS) l[i] = 0ull;
-    bitonic_desc_u64(l, npad, tid, MERGE_THREADS);
-    const int total = min(off, a.k);
+    if (n > k) { Tmin = select(n); n = k; }
+
+    if (a.zero_words && q == 0 && tid < ST_SYNC_WORDS) a.zero_words[tid] = 0u;
     if (a.final_level) {
-        for (int t = tid; t < a.k; t += MERGE_THREADS) {
-            const u64 e = t < total ? l[t] : 0ull;
-            const bool valid = t < total;
-            a.D[(size_t)q * a.k + t] = valid ? key2f((u32)(e >> 32)) : -FLT_MAX;
-            a.I[(size_t)q * a.k + t] = valid ? a.id_base + (long long)(0xFFFFFFFFu - (u32)e) : -1ll;
+        // order the survivors by rank counting and write (D, I); positions past n are padding
+        for (int t = tid; t < k; t += NT) {
+            if (t < n) {
+                const u64 v = l[t];
+                int r = 0;
+                for (int j = 0; j < n; ++j) r += (l[j] > v) || (l[j] == v && j < t);
+                a.D[(size_t)q * k + r] = key2f((u32)(v >> 32));
+                a.I[(size_t)q * k + r] = a.id_base + (long long)(0xFFFFFFFFu - (u32)v);
+            } else {
+                a.D[(size_t)q * k + t] = -FLT_MAX;
+                a.I[(size_t)q * k + t] = -1ll;
+            }
         }
     } else {
-        u64* dst = a.out + ((size_t)g * a.nq_pad + q) * a.k;
-        for (int t = tid; t < total; t += MERGE_THREADS) dst[t] = l[t];
+        u64* dst = a.out + (size_t)q * k;
+        for (int t = tid; t < n; t += NT) dst[t] = l[t];
+        if (a.thr_out && n >= k && Tmin == 0ull) {
+            // exactly k gathered and never cut: their minimum by a block reduction
+            u64 mn = ~0ull;
+            for (int t = tid; t < n; t += NT) mn = l[t] < mn ? l[t] : mn;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const u64 a2 = __shfl_xor(mn, o);
+                mn = a2 < mn ? a2 : mn;
+            }
+            if (lane == 0) sRed[wave] = mn;
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < NWV; ++w) mn = sRed[w] < mn ? sRed[w] : mn;
+                Tmin = mn;
+            }
+        }
         if (tid == 0) {
-            a.out_cnt[(size_t)g * a.nq_pad + q] = (u32)total;
-            if (a.thr_out) a.thr_out[q] = total >= a.k ? (u32)(l[a.k - 1] >> 32) : 0u;
+            a.out_cnt[q] = (u32)n;
+            if (a.thr_out) a.thr_out[q] = n >= k ? (u32)(Tmin >> 32) : 0u;
         }
     }
 }
@@ -1366,6 +1834,10 @@ ScanCfg make_cfg() {
 // tiles) plus 2 per extra 128 rows of the tile.
 template <int EPL>
 ScanCfg pick_shape(long long nq) {
+    static const char* sv = getenv("OTTER_SCAN_SMALL");      // A/B switch for tuning runs (nq <= 32)
+    if (nq <= 32 && sv && sv[0] == 'a') return make_cfg<4, 1, 1, 1, 32, 7, EPL>();   // 128 rows, 7 x 20 KB
+    if (nq <= 32 && sv && sv[0] == 'b') return make_cfg<4, 1, 2, 1, 32, 4, EPL>();   // 256 rows, 4 x 36 KB
+    if (nq <= 32 && sv && sv[0] == 'c') return make_cfg<4, 1, 1, 1, 32, 5, EPL>();   // 128 rows, 5 x 20 KB
     if (nq <= 32) return make_cfg<4, 1, 1, 1, 64, 3, EPL>();
     if (nq <= 64) return make_cfg<4, 1, 1, 2, 64, 3, EPL>();
     static const char* v = getenv("OTTER_SCAN_VARIANT");   // A/B switch for tuning runs
@@ -1383,6 +1855,20 @@ int pick_cfg(long long nq, int k, ScanCfg* out) {
     else if (k <= 2048) *out = pick_shape<64>(nq);
     else return set_err(OTTER_EINVAL, "search: k=%d exceeds OTTER_MAX_K=%d", k, OTTER_MAX_K);
     return OTTER_OK;
+}
+
+template <int G, int EPL, int BK, int NSTAGE>
+void launch_stream(const StreamArgs& a, int grid, hipStream_t st) {
+    auto kern = stream_kernel<G, EPL, BK, NSTAGE>;
+    const int lds = 4 * NSTAGE * st_slot(G, BK) + 67 * (int)sizeof(u32);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
 }
 
 struct Scan16Cfg {
@@ -1446,17 +1932,18 @@ struct otter_index {
     bool xh_failed = false, one_prod_off = false;
     long long last_stage0_unproven = 0;
     otter::DevBuf qs, qnorm2, cD, cI, rs, rscnt, flags, fb_q, fb_D, fb_I;
-    otter::DevBuf qpad, cand, cnt, lvl[2], lvlcnt[2], smp, smpcnt, thr0, io_q, io_D, io_I;
+    otter::DevBuf qpad, cand, cnt, lvl[2], lvlcnt[2], smp, smpcnt, thr0, io_q, io_D, io_I, bmax, sync;
+    bool sync_dirty = true;         // the stream kernel's counters are not known to be zero
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
 };
 
 // Scratch of otter_index_search_noalloc (include/otter_hip.h): one fixed region per GPU, part of the code
-// object, so the entry point never allocates.  Layout = the bump allocation order of search_chunk() for the
-// largest shape that entry point accepts (32 queries, k <= 128, d <= 4096, 256 strips):
-//   qpad 32 x 4096 x 4 | cand 256 x 32 x 384 x 8 | cnt | sample list, count, threshold | merge level lists
+// object, so the entry point never allocates.  Layout = 256 bytes for the stream kernel's counters, then the bump
+// allocation order of search_chunk_stream() for the largest shape that entry point accepts (32 queries, k <= 128,
+// d <= 4096, 256 strips):  qpad 32 x 4096 x 4 | cand 256 x 32 x 512 x 8 | cnt | block maxima 32 x 1024 x 8
 constexpr int NA_MAX_NQ = 32, NA_MAX_K = 128, NA_MAX_LD = 4096, NA_MAX_STRIPS = 256;
-constexpr size_t NA_SCRATCH_BYTES = 25ull << 20;      // 25 MiB (the layout above needs 24.8 MiB)
+constexpr size_t NA_SCRATCH_BYTES = 34ull << 20;      // 34 MiB (32 queries: 256 strips x 32 x 512 composites = 32 MiB + the rest)
 static __device__ __align__(256) unsigned char scratch[NA_SCRATCH_BYTES];
 
 namespace {
@@ -1528,74 +2015,63 @@ int index_reserve_rows(otter_index* ix, long long need_rows, hipStream_t st) {
     return OTTER_OK;
 }
 
-// Merge the per-strip candidate lists of one scan, level by level (one workgroup sorts at most
-// MAX_SELECT composites).  The last level also takes one more sorted list (ex), if given.  final: write
-// (D, I); otherwise leave ONE sorted list of <= k composites per query in list_out (which may be ex
-// itself) and the score key of each query's k-th best in thr_out.
+// Merge the per-strip candidate lists of one scan (one launch, one workgroup per query).  An extra unsorted
+// list (ex) may join.  final: write sorted (D, I); otherwise leave ONE unsorted list of <= k composites per
+// query in list_out (which may be ex itself: a workgroup has read its query's ex list before it writes) and
+// the score key of each query's k-th best in thr_out.
+template <int NT, int CAPL>
+int launch_merge(int device, const MergeArgs& ma, long long nq, hipStream_t st) {
+    const size_t lds = (size_t)(CAPL + 256) * sizeof(u64) + (size_t)(MERGE_MAX_STRIPS + 2 + 256) * sizeof(int) +
+                       (size_t)(2 * (NT / 64) + 1) * sizeof(u64) + 8 * sizeof(int);
+    auto kern = merge_kernel<NT, CAPL>;
+    static bool attr_set[64] = {};
+    if (device >= 0 && device < 64 && !attr_set[device]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set[device] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(NT), lds, st, ma);
+    OTTER_HIP_TRY(hipGetLastError());
+    return OTTER_OK;
+}
+
 int run_merge(otter_index* ix, const u64* in, const u32* in_cnt, int cap_in, int S_in, long long nq, long long nq_pad,
               int k, bool final, float* D, long long* I, const u64* ex, const u32* ex_cnt, u64* list_out,
-              u32* list_cnt, u32* thr_out, hipStream_t st, int take_first = 0, Scratch* sc = nullptr) {
-    Scratch own;
-    if (!sc) sc = &own;
-    int take = take_first > 0 ? take_first : k;      // first level only; later levels read lists of <= k
-    int fan = std::min(MERGE_MAX_STRIPS, std::max(2, (MAX_SELECT - (ex ? k : 0)) / take));
-    int pp = 0, rc;
-    for (;;) {
-        const int S_out = (S_in + fan - 1) / fan;
-        const bool last = S_out == 1;
-        MergeArgs ma;
-        ma.in = in;
-        ma.in_cnt = in_cnt;
-        ma.out = nullptr;
-        ma.out_cnt = nullptr;
-        ma.D = D;
-        ma.I = I;
-        ma.id_base = ix->id_base;
-        ma.cap_in = cap_in;
-        ma.S_in = S_in;
-        ma.fan = fan;
-        ma.take = take;
-        ma.nq_pad = (int)nq_pad;
-        ma.k = k;
-        ma.final_level = (last && final) ? 1 : 0;
-        ma.ex = last ? ex : nullptr;
-        ma.ex_cnt = last ? ex_cnt : nullptr;
-        ma.thr_out = nullptr;
-        ma.npad = next_pow2(std::max(2, std::min(S_in, fan) * take + (ma.ex ? k : 0)));
-        ma.npad = std::max(ma.npad, next_pow2(k));
-        if (!ma.final_level) {
-            if (last) {
-                ma.out = list_out;
-                ma.out_cnt = list_cnt;
-                ma.thr_out = thr_out;
-            } else {
-                void *lp = nullptr, *lc = nullptr;
-                if ((rc = sc->get(ix->lvl[pp], (size_t)S_out * nq_pad * k * sizeof(u64), &lp))) return rc;
-                if ((rc = sc->get(ix->lvlcnt[pp], (size_t)S_out * nq_pad * sizeof(u32), &lc))) return rc;
-                ma.out = (u64*)lp;
-                ma.out_cnt = (u32*)lc;
-            }
-        }
-        const size_t lds = (size_t)ma.npad * sizeof(u64) + (size_t)(MERGE_MAX_STRIPS + 4 + 32 + 4) * sizeof(int);
-        static bool attr_set[64] = {};
-        if (ix->device < 64 && !attr_set[ix->device]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(merge_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      MAX_SELECT * 2 * (int)sizeof(u64) + (MERGE_MAX_STRIPS + 40) * (int)sizeof(int));
-            attr_set[ix->device] = true;
-        }
-        hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq, (unsigned)S_out), dim3(MERGE_THREADS), lds, st, ma);
-        OTTER_HIP_TRY(hipGetLastError());
-        if (last) break;
-        in = ma.out;
-        in_cnt = ma.out_cnt;
-        cap_in = k;
-        take = k;
-        fan = std::min(MERGE_MAX_STRIPS, std::max(2, MAX_SELECT / k - (ex ? 1 : 0)));
-        S_in = S_out;
-        pp ^= 1;
-    }
-    return OTTER_OK;
+              u32* list_cnt, u32* thr_out, hipStream_t st, int take_first = 0, Scratch* sc = nullptr,
+              u32* zero_words = nullptr) {
+    (void)sc;
+    const int take = take_first > 0 ? take_first : std::min(k, cap_in);
+    MergeArgs ma;
+    ma.in = in;
+    ma.in_cnt = in_cnt;
+    ma.out = final ? nullptr : list_out;
+    ma.out_cnt = final ? nullptr : list_cnt;
+    ma.D = D;
+    ma.I = I;
+    ma.id_base = ix->id_base;
+    ma.cap_in = cap_in;
+    ma.S_in = S_in;
+    ma.take = take;
+    ma.nq_pad = (int)nq_pad;
+    ma.k = k;
+    ma.final_level = final ? 1 : 0;
+    ma.ex = ex;
+    ma.ex_cnt = ex_cnt;
+    ma.thr_out = final ? nullptr : thr_out;
+    ma.zero_words = zero_words;
+    // Four waves per query (cheap barriers; the pool lives in registers during a select), pool sized to the
+    // job: a smaller pool lets more workgroups share a CU's LDS.
+    static const char* mv = getenv("OTTER_MERGE_VARIANT");      // A/B switch for tuning runs
+    if (mv && mv[0] == 'a') return launch_merge<1024, MAX_SELECT>(ix->device, ma, nq, st);
+    if (mv && mv[0] == 'b') return launch_merge<512, MAX_SELECT>(ix->device, ma, nq, st);
+    if ((long long)S_in * take + k <= 1024) return launch_merge<256, 1024>(ix->device, ma, nq, st);
+    if (mv && mv[0] == 'c') return launch_merge<512, 4096>(ix->device, ma, nq, st);
+    // few queries: latency counts, 16 waves gather the strips in parallel; many queries: throughput counts, small
+    // workgroups share a CU (measured: 1 ... 256 queries 1024 threads, 2214 queries 256 threads)
+    if (nq < 1024 && k + take <= MAX_SELECT) return launch_merge<1024, MAX_SELECT>(ix->device, ma, nq, st);
+    if (k + take <= 4096) return launch_merge<256, 4096>(ix->device, ma, nq, st);
+    if (k + take > MAX_SELECT)
+        return set_err(OTTER_EINVAL, "merge: k=%d + %d entries per strip exceed the %d-entry pool", k, take, MAX_SELECT);
+    return launch_merge<512, MAX_SELECT>(ix->device, ma, nq, st);
 }
 
 struct Scratch;
@@ -1606,6 +2082,82 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
 int split_kc(int k, int mode, int d);
 int ensure_split_planes(otter_index* ix, hipStream_t st);
 int ensure_hi_plane(otter_index* ix, hipStream_t st);
+
+// device-side dirty flags of the static scratch's stream-kernel counters (shared by every index of a GPU)
+bool g_scratch_sync_dirty[64] = {};
+
+// at most 32 queries, k <= 128: the stream kernel + one merge (no sample pass, no pad kernel for aligned rows)
+int search_chunk_stream(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st,
+                        Scratch* sc) {
+    constexpr int EPL = 8, CAP = EPL * 64;
+    const int G = nq <= 4 ? 1 : nq <= 8 ? 2 : nq <= 16 ? 4 : 8;
+    const int nqp = 4 * G;
+    const int total_tiles = (int)((ix->n + ST_BM - 1) / ST_BM);
+    int strips = std::min(std::min(ix->ncu, NA_MAX_STRIPS), total_tiles);
+    strips = std::max(strips, 1);
+    int rc;
+    void *w_qpad = nullptr, *w_cand, *w_cnt, *w_bmax, *w_sync;
+    const bool q_in_place = ix->ld == ix->d && ((uintptr_t)qd & 15) == 0;
+    if (!q_in_place && (rc = sc->get(ix->qpad, (size_t)nqp * ix->ld * sizeof(float), &w_qpad))) return rc;
+    if ((rc = sc->get(ix->cand, (size_t)strips * nqp * CAP * sizeof(u64), &w_cand))) return rc;
+    if ((rc = sc->get(ix->cnt, (size_t)strips * nqp * sizeof(u32), &w_cnt))) return rc;
+    if ((rc = sc->get(ix->bmax, (size_t)32 * 4 * NA_MAX_STRIPS * sizeof(u64), &w_bmax))) return rc;
+    const void* sync_before = ix->sync.p;
+    if (sc->fixed) w_sync = sc->fixed;          // reserved head of the static scratch (no other layout touches it)
+    else if ((rc = sc->get(ix->sync, 64 * sizeof(u32), &w_sync))) return rc;
+    bool& dirty = sc->fixed ? g_scratch_sync_dirty[ix->device] : ix->sync_dirty;
+    if (!sc->fixed && ix->sync.p != sync_before) dirty = true;       // a fresh allocation is not zero
+    if (dirty) OTTER_HIP_TRY(hipMemsetAsync(w_sync, 0, 64 * sizeof(u32), st));
+    dirty = true;                                                     // until this search's merge has been enqueued
+    if (!q_in_place) {
+        const long long total = (long long)nqp * ix->ld;
+        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, qd, (float*)w_qpad, nq,
+                           (long long)nqp, ix->d, ix->ld);
+    }
+    StreamArgs sa;
+    sa.X = ix->x;
+    sa.Q = q_in_place ? qd : (const float*)w_qpad;
+    sa.q_rows = q_in_place ? (int)nq : nqp;
+    sa.cand = (u64*)w_cand;
+    sa.cnt = (u32*)w_cnt;
+    sa.n = ix->n;
+    sa.ld = ix->ld;
+    sa.nq = (int)nq;
+    sa.k = k;
+    sa.strips = strips;
+    sa.total_tiles = total_tiles;
+    // the exchange needs k block maxima at least (4 per workgroup); a strip of one tile gains nothing from it
+    static const char* no_seed = getenv("OTTER_NO_SAMPLE");
+    sa.seed = (!no_seed && 4 * strips >= 2 * k && total_tiles >= 2 * strips) ? 1 : 0;
+    sa.bmax = (u64*)w_bmax;
+    sa.sync = (u32*)w_sync;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    const bool timed = ix->timing && ix->ev_pending.size() < 4096 && !sc->fixed;
+    if (timed) {
+        if (!ix->ev_free.empty()) {
+            ev = ix->ev_free.back();
+            ix->ev_free.pop_back();
+        } else {
+            OTTER_HIP_TRY(hipEventCreate(&ev.first));
+            OTTER_HIP_TRY(hipEventCreate(&ev.second));
+        }
+        OTTER_HIP_TRY(hipEventRecord(ev.first, st));
+    }
+    // (ring depth by LDS: 4 waves x slots x (8 KiB + queries))
+    if (G == 1) launch_stream<1, EPL, 32, 4>(sa, strips, st);
+    else if (G == 2) launch_stream<2, EPL, 32, 4>(sa, strips, st);
+    else if (G == 4) launch_stream<4, EPL, 32, 3>(sa, strips, st);
+    else launch_stream<8, EPL, 32, 3>(sa, strips, st);
+    OTTER_HIP_TRY(hipGetLastError());
+    if (timed) {
+        OTTER_HIP_TRY(hipEventRecord(ev.second, st));
+        ix->ev_pending.push_back(ev);
+    }
+    rc = run_merge(ix, (const u64*)w_cand, (const u32*)w_cnt, CAP, strips, nq, nqp, k, true, D, I, nullptr, nullptr, nullptr,
+                   nullptr, nullptr, st, 0, sc, (u32*)w_sync);
+    if (rc == OTTER_OK) dirty = false;                                // the merge leaves the counters zero
+    return rc;
+}
 
 // one scan + merge over queries [qd, qd + nq) (device pointers), results to device D/I
 int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st,
@@ -1636,6 +2188,10 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
             }
         }
     }
+    static const char* no_stream = getenv("OTTER_NO_STREAM");
+    // (measured, 1M x 768: 1 ... 8 queries 0.51 ms, 16 queries 0.54 ms per search; at 17 ... 32 queries the 4x4x1
+    // products cost more than scan_kernel's 32x32x2 tile: 0.76 against 0.69 ms)
+    if (nq <= 16 && k <= 128 && !no_stream) return search_chunk_stream(ix, qd, nq, k, D, I, st, sc);
     ScanCfg cfg;
     int rc = pick_cfg(nq, k, &cfg);
     if (rc) return rc;
@@ -1649,6 +2205,8 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
     // [0, n_s); the main scan over [n_s, n) starts every strip from that threshold.  Exact: the
     // sample rows have the smallest ids, so a later row that only ties the k-th key ranks behind it.
     static const char* no_sample = getenv("OTTER_NO_SAMPLE");
+    // one tile per workgroup of a full launch, at least 64 k rows
+    const int wgs_all = std::max(1, ix->ncu / qtiles);
     const long long n_s = round_up64(std::max<long long>(16384, 64ll * k), 256);
     const bool sample = !no_sample && nq <= 64 && ix->n >= 12 * n_s;
     const int sample_tiles = sample ? (int)(n_s / cfg.bm) : 0;
@@ -1657,8 +2215,10 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
     int strips = std::max(1, ix->ncu / qtiles);
     strips = std::min(strips, main_tiles);
     if (sc->fixed) strips = std::min(strips, NA_MAX_STRIPS);
-    // few enough sample strips for a one-level merge (fan >= 64 up to k = 126; beyond, run_merge adds a level)
-    int strips_s = sample ? std::min(std::min(std::max(1, ix->ncu / qtiles), sample_tiles), 64) : 0;
+    int strips_s = sample ? std::min(std::min(wgs_all, sample_tiles), 64) : 0;
+    // one-tile sample strips may keep all their rows (<= CAP): no compaction in the scan, the merge selects
+    const bool sample_whole = sample && sample_tiles == strips_s && cfg.bm <= cfg.cap && k + cfg.bm <= MAX_SELECT &&
+                              (long long)strips_s * cfg.bm <= 4096;
 
     void *w_qpad, *w_cand, *w_cnt, *w_smp = nullptr, *w_smpcnt = nullptr, *w_thr0 = nullptr;
     if ((rc = sc->get(ix->qpad, (size_t)nq_pad * ix->ld * sizeof(float), &w_qpad))) return rc;
@@ -1670,7 +2230,9 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
         if ((rc = sc->get(ix->thr0, (size_t)nq_pad * sizeof(u32), &w_thr0))) return rc;
     }
 
-    {
+    // queries whose rows already have the index's row length are read in place (16-byte aligned for the LDS-DMA)
+    const bool q_in_place = ix->ld == ix->d && ((uintptr_t)qd & 15) == 0;
+    if (!q_in_place) {
         const long long total = nq_pad * ix->ld;
         const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
         hipLaunchKernelGGL(pad_rows_kernel, dim3(grid), dim3(256), 0, st, qd, (float*)w_qpad, nq, nq_pad, ix->d,
@@ -1679,7 +2241,9 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
 
     ScanArgs sa;
     sa.X = ix->x;
-    sa.Q = (const float*)w_qpad;
+    sa.Q = q_in_place ? qd : (const float*)w_qpad;
+    sa.q_rows = q_in_place ? (int)nq : (int)nq_pad;
+    sa.skip_final = 0;
     sa.cand = (u64*)w_cand;
     sa.cnt = (u32*)w_cnt;
     sa.n = ix->n;
@@ -1708,11 +2272,13 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
         sa.total_tiles = sample_tiles;
         sa.tile_begin = 0;
         sa.thr0 = nullptr;
+        sa.skip_final = sample_whole ? 1 : 0;
         cfg.launch(sa, qtiles * strips_s, cfg.lds, st);
         OTTER_HIP_TRY(hipGetLastError());
+        sa.skip_final = 0;
         if ((rc = run_merge(ix, (const u64*)w_cand, (const u32*)w_cnt, cfg.cap, strips_s, nq, nq_pad, k, false,
                             nullptr, nullptr, nullptr, nullptr, (u64*)w_smp, (u32*)w_smpcnt, (u32*)w_thr0,
-                            st, 0, sc)))
+                            st, sample_whole ? cfg.bm : 0, sc)))
             return rc;
     }
     sa.strips = strips;
@@ -2260,6 +2826,7 @@ int otter_index_search_noalloc(otter_index* ix, const float* q, int64_t nq, int 
     Scratch sc;
     sc.fixed = g_scratch_ptr[ix->device];       // resolved by otter_index_create on this device
     sc.fixed_bytes = NA_SCRATCH_BYTES;
+    sc.used = 256;                              // the first 256 bytes hold the stream kernel's counters
     if (!sc.fixed) return set_err(OTTER_ESTATE, "search_noalloc: static scratch of device %d was not resolved", ix->device);
     return search_chunk(ix, q, nq, k, D, (long long*)I, st, &sc);
 }
@@ -2475,6 +3042,8 @@ void otter_index_destroy(otter_index* ix) {
     ix->smp.release();
     ix->smpcnt.release();
     ix->thr0.release();
+    ix->bmax.release();
+    ix->sync.release();
     ix->io_q.release();
     ix->io_D.release();
     ix->io_I.release();
