@@ -524,12 +524,28 @@ struct StreamArgs {
     u32* sync;           // [0] arrivals, [1] ready, [2..33] thresholds (keys); zero at launch, zeroed again by the merge
 };
 
-constexpr int ST_BM = 256, ST_HOLD = 3, ST_SYNC_WORDS = 34;
+constexpr int ST_BM = 256, ST_SYNC_WORDS = 34;
 constexpr int st_qinstr(int G, int BK) { return (4 * G * BK * 4 + 1023) / 1024; }              // LDS-DMA instructions for the queries
 constexpr int st_slot(int G, int BK) { return 64 * BK * 4 + st_qinstr(G, BK) * 1024; }        // per wave and stage
 constexpr int st_ips(int G, int BK) { return BK / 4 + st_qinstr(G, BK); }                     // LDS-DMA instructions per wave and stage
 
 // k-th largest of the n <= 64 * EPL composites in x (unique, zero = empty): radix select by ballots
+// key of the k-th largest composite (high words only; equal keys may straddle the cut, which a ">=" filter
+// tolerates): 32 ballot rounds
+template <int EPL>
+__device__ __forceinline__ u32 wave_kth_key(const u64 (&x)[EPL], int k) {
+    u32 T = 0u;
+    for (int b = 31; b >= 0; --b) {
+        const u32 c = T | (1u << b);
+        int cntv = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) cntv += __popcll(__ballot((u32)(x[e] >> 32) >= c));
+        if (cntv >= k) T = c;
+        if (cntv == k) break;        // (no further bit can be set without dropping below k)
+    }
+    return T;
+}
+
 template <int EPL>
 __device__ __forceinline__ u64 wave_kth(const u64 (&x)[EPL], int k) {
     u64 T = 0ull;
@@ -558,6 +574,7 @@ __device__ __forceinline__ u64 wave_kth(const u64 (&x)[EPL], int k) {
 template <int G, int EPL, int ST_BK, int ST_NSTAGE>
 __global__ __launch_bounds__(256) void stream_kernel(StreamArgs a) {
     constexpr int NQP = 4 * G;                 // query columns computed (padded to whole 4x4 blocks)
+    constexpr int ST_HOLD = G <= 2 ? 6 : 4;    // tiles whose scores wait in registers for the thresholds (4 G per tile)
     constexpr int CAP = EPL * 64;
     constexpr int QI = st_qinstr(G, ST_BK), ST_SLOT = st_slot(G, ST_BK), ST_IPS = st_ips(G, ST_BK);
     constexpr int CH = ST_BK / 4;              // 16-byte chunks per row of a stage
@@ -659,6 +676,7 @@ __global__ __launch_bounds__(256) void stream_kernel(StreamArgs a) {
     f32x4 held[ST_HOLD][G];
     int nheld = 0, held_tile0 = t0;
     bool have_thr = a.seed == 0;     // no exchange: thresholds are learned locally from the start
+    bool got_global = a.seed == 0;   // the exchanged thresholds have been taken over (or there are none to wait for)
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -764,26 +782,29 @@ __global__ __launch_bounds__(256) void stream_kernel(StreamArgs a) {
                     int valid = 0;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) valid += __popcll(__ballot(x[e] != 0ull));
-                    const u64 T = valid >= a.k ? wave_kth<16>(x, a.k) : 0ull;
+                    const u32 T = valid >= a.k ? wave_kth_key<16>(x, a.k) : 0u;
                     if (lane == 0)
-                        __hip_atomic_store(a.sync + 2 + q, (u32)(T >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(a.sync + 2 + q, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 wait_vmcnt<0>();
                 wg_barrier();
                 if (tid == 0) __hip_atomic_store(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        if (!have_thr) {
+        if (!got_global) {
             // thresholds there yet?  (one sc1 poll per tile boundary; nobody waits)
             if (wave == 0) {
                 const u32 r = __hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (r && lane < a.nq)
-                    sThr[lane] = __hip_atomic_load(a.sync + 2 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (r && lane < a.nq) {
+                    const u32 t = __hip_atomic_load(a.sync + 2 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sThr[lane] = max(sThr[lane], t);
+                }
                 if (lane == 0) sFlag[1] = r;
             }
             wg_barrier();
             const bool ready = sFlag[1] != 0u;
-            if (ready || nheld == ST_HOLD || tile + 1 == t1) {
+            got_global = ready;
+            if (!have_thr && (ready || nheld == ST_HOLD || tile + 1 == t1)) {
                 // flush the held tiles through the filter (without thresholds: one tile at a time, compacting)
 #pragma unroll
                 for (int h = 0; h < ST_HOLD; ++h) {
@@ -795,6 +816,8 @@ __global__ __launch_bounds__(256) void stream_kernel(StreamArgs a) {
                 }
                 nheld = 0;
                 have_thr = true;
+            } else if (have_thr && __builtin_amdgcn_readfirstlane(sFlag[0])) {
+                compact_pass(false);
             }
         } else if (__builtin_amdgcn_readfirstlane(sFlag[0])) {
             compact_pass(false);
@@ -822,6 +845,260 @@ __global__ __launch_bounds__(256) void stream_kernel(StreamArgs a) {
 // (accumulator rows), streamed over a strip of corpus tiles, and scan_kernel's epilogue
 // (per-query threshold in LDS, candidate buffers, wave radix compaction).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ------------------------------------------------------------------ stream kernel, bf16 storage (at most 16 queries)
+// stream_kernel's structure on an OTTER_BF16 index: a wave streams its own 64 rows of every 256-row tile, one
+// 64-element K-slab (128 B per row; the planes are tile-blocked, so a wave's rows of a slab are 8 KiB of
+// consecutive bytes) per stage, v_mfma_f32_16x16x32_bf16 with scan16_kernel<0>'s operand roles and k order
+// (identical scores), the same threshold exchange, candidate path and merge.  X and Q are the bf16 planes;
+// a.ld is the row length in elements.
+template <int EPL, int ST_NSTAGE>
+__global__ __launch_bounds__(256) void stream16_kernel(StreamArgs a) {
+    constexpr int NQP = 16;                    // query columns of one 16x16x32 block
+    constexpr int G = 4;                       // 16-row blocks of a wave's 64 rows
+    constexpr int ST_HOLD = 6;                 // tiles whose scores wait in registers for the thresholds (16 per tile)
+    constexpr int ST_BK = 32;                  // (a stage = one 64-element K-slab = 128 bytes per row, as 32 floats are)
+    constexpr int CAP = EPL * 64;
+    constexpr int QI = 2, ST_SLOT = 64 * 128 + QI * 1024, ST_IPS = 8 + QI;     // 16 query rows x 128 B
+    constexpr int CH = ST_BK / 4;              // 16-byte chunks per row of a stage
+    constexpr int RPI = 64 / CH;               // rows per LDS-DMA instruction
+    static_assert(CAP - ST_BM >= 128, "candidate buffer too small");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32* sCnt = reinterpret_cast<u32*>(smem + 4 * ST_NSTAGE * ST_SLOT);
+    u32* sThr = sCnt + 32;
+    u32* sFlag = sThr + 32;       // [0] compaction wanted, [1] thresholds ready, [2] this workgroup selects
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int strip = blockIdx.x;
+    const int t0 = (int)(((long long)strip * a.total_tiles) / a.strips);
+    const int t1 = (int)(((long long)(strip + 1) * a.total_tiles) / a.strips);
+    const int KS = a.ld / 64;                  // a.ld = row length in bf16 elements (multiple of 64)
+    if (tid < 32) {
+        sCnt[tid] = 0;
+        sThr[tid] = 0u;            // accept everything (key >= 0) until a threshold is known
+    }
+    if (tid < 3) sFlag[tid] = 0;
+    u64* candBase = a.cand + (size_t)strip * NQP * CAP;
+
+    // ---- producer: this wave's 64 rows x BK floats (1 KiB per instruction) + the queries' BK floats
+    // LDS image: [row][CH chunks of 16 B], chunk position p of row r holds global chunk p ^ swz(r), swz chosen so
+    // that the rows one ds_read_b128 lane group touches fall on distinct 16-byte slots of the 256-byte bank row
+    auto swz = [](int r) { return CH == 16 ? (r & 15) : ((r >> 1) & 7); };
+    const u32 lds0 = (u32)(uintptr_t)(AS3 char*)smem + (u32)wave * (ST_NSTAGE * ST_SLOT);
+    u32 voffA[CH], voffQ[QI];
+    // (tile-blocked planes: the K-slab of a 256-row tile is one 32 KiB block of 256 rows x 128 B, plane_index)
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int r = RPI * i + lane / CH;
+        voffA[i] = (u32)(wave * 64 + r) * 128u + (u32)(((lane % CH) ^ swz(r)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < QI; ++i) {
+        const int r = RPI * i + lane / CH;       // rows past the batch are zero rows of the query plane
+        voffQ[i] = (u32)r * 128u + (u32)(((lane % CH) ^ swz(r)) << 4);
+    }
+    const long long total_stages = (long long)(t1 - t0) * KS;
+    int it_tile = t0, it_ks = 0;
+    long long it_f = 0;
+    auto issue_stage = [&]() {
+        if (it_f < total_stages) {
+            const char* gA = reinterpret_cast<const char*>(a.X) + ((size_t)((u32)it_tile * (u32)KS + (u32)it_ks) << 15);
+            const char* gQ = reinterpret_cast<const char*>(a.Q) + ((size_t)(u32)it_ks << 15);
+            const u32 l = lds0 + (u32)(it_f % ST_NSTAGE) * ST_SLOT;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) dma16s_stream(gA, voffA[i], l + i * 1024);
+#pragma unroll
+            for (int i = 0; i < QI; ++i) dma16s(gQ, voffQ[i], l + CH * 1024 + i * 1024);
+            ++it_f;
+            if (++it_ks == KS) { it_ks = 0; ++it_tile; }
+        }
+    };
+
+    // ---- candidate path.  Lane l holds, per 16-row block g, the scores of rows 16 g + 4 (l >> 4) + i (i = 0..3)
+    // of this wave's 64 for query l & 15
+    const int rsub = wave * 64 + 4 * (lane >> 4);
+    auto append_tile = [&](const f32x4 (&sc)[G], int tile) {
+        const int q = lane & 15;
+        const u32 thr = sThr[q];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const long long row0 = (long long)tile * ST_BM + rsub + 16 * g;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32 key = f2key(sc[g][i]);
+                if (q < a.nq && key >= thr && row0 + i < a.n) {
+                    const u32 pos = atomicAdd(&sCnt[q], 1u);
+                    if (pos < (u32)CAP)
+                        candBase[(u32)q * (u32)CAP + pos] = ((u64)key << 32) | (u64)(0xFFFFFFFFu - (u32)(row0 + i));
+                    if (pos + 1 > (u32)(CAP - ST_BM)) sFlag[0] = 1;
+                }
+            }
+        }
+    };
+    auto compact_pass = [&](bool final_pass) {      // workgroup-wide; every wave calls it at the same point
+        wait_vmcnt<0>();
+        wg_barrier();
+        for (int q = wave; q < NQP; q += 4) {
+            const int n = (int)min(sCnt[q], (u32)CAP);
+            const bool need = final_pass ? (n > a.k) : (n > CAP - ST_BM);
+            if (need) {
+                const u64 T = wave_compact<EPL>(candBase + (size_t)q * CAP, n, a.k, lane);
+                if (lane == 0) {
+                    sCnt[q] = (u32)a.k;
+                    sThr[q] = max(sThr[q], (u32)(T >> 32));
+                }
+            }
+        }
+        if (tid == 0) sFlag[0] = 0;
+        wait_vmcnt<0>();
+        wg_barrier();
+    };
+
+    f32x4 acc[G];
+    f32x4 held[ST_HOLD][G];
+    int nheld = 0, held_tile0 = t0;
+    bool have_thr = a.seed == 0;     // no exchange: thresholds are learned locally from the start
+    bool got_global = a.seed == 0;   // the exchanged thresholds have been taken over (or there are none to wait for)
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s2 = 0; s2 < ST_NSTAGE - 1; ++s2) issue_stage();
+
+    const u32 fr = (u32)(lane & 15), fq = (u32)(lane >> 4);
+    const u32 rowoff = fr * 128u;
+    const u32 rswz = (u32)swz((int)fr);          // (swz(16 g + fr) == swz(fr))
+    long long f = 0;
+    for (int tile = t0; tile < t1; ++tile) {
+        for (int ks = 0; ks < KS; ++ks, ++f) {
+            // stage f (this wave's own loads) has landed once at most NSTAGE-2 younger stages are outstanding
+            if (total_stages - 1 - f >= ST_NSTAGE - 2) wait_vmcnt<(ST_NSTAGE - 2) * ST_IPS>();
+            else wait_vmcnt<0>();
+            // the slot of stage f-1 was read by this wave only, and those reads have returned (their values fed
+            // the products above): refill it with stage f + NSTAGE - 1
+            wait_lgkm0();
+            issue_stage();
+            const char* sA = smem + wave * (ST_NSTAGE * ST_SLOT) + (int)(f % ST_NSTAGE) * ST_SLOT;
+            const char* sQ = sA + CH * 1024;
+            // two k-steps of 32 per slab; operand roles as in scan16_kernel<0> (corpus rows = A, queries = B), so the
+            // scores are that kernel's, bit for bit
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                const u32 co = ((4u * ks2 + fq) ^ rswz) << 4;
+                const float4 qf = *reinterpret_cast<const float4*>(sQ + rowoff + co);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float4 xf = *reinterpret_cast<const float4*>(sA + g * 16 * 128 + rowoff + co);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf), __builtin_bit_cast(bf16x8, qf),
+                                                                     acc[g], 0, 0, 0);
+                }
+            }
+        }
+        // ---- end of a tile
+        if (have_thr) {
+            append_tile(acc, tile);
+        } else {
+            if (nheld == 0) held_tile0 = tile;
+#pragma unroll
+            for (int h = 0; h < ST_HOLD; ++h)
+                if (h == nheld)
+#pragma unroll
+                    for (int g = 0; g < G; ++g) held[h][g] = acc[g];
+            ++nheld;
+        }
+        if (a.seed && tile == t0) {
+            // publish the best row of this wave's first tile, per query (composites; 0 = no valid row)
+            {
+                const int q = lane & 15;
+                u64 c = 0ull;
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const long long row0 = (long long)tile * ST_BM + rsub + 16 * g;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u64 v = (q < a.nq && row0 + i < a.n)
+                                          ? (((u64)f2key(acc[g][i]) << 32) | (u64)(0xFFFFFFFFu - (u32)(row0 + i))) : 0ull;
+                        c = v > c ? v : c;
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o >= 16; o >>= 1) {     // over the lanes that hold this query
+                    const u64 v = __shfl_xor(c, o);
+                    c = v > c ? v : c;
+                }
+                if (lane < 16 && q < a.nq)
+                    __hip_atomic_store(a.bmax + (size_t)q * (4 * a.strips) + 4 * strip + wave, c, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+            wait_vmcnt<0>();            // this wave's stores have left (once per launch: the ring drains with them)
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        wg_barrier();                   // tile boundary: every wave has appended / published
+        if (a.seed && tile == t0) {
+            if (tid == 0) {
+                const u32 old = __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sFlag[2] = (old == (u32)a.strips - 1u) ? 1u : 0u;
+            }
+            wg_barrier();
+            if (sFlag[2]) {
+                // last arrival: every block maximum is published.  Wave w selects for queries w, w + 4, ...
+                const int M = 4 * a.strips;          // <= 1024 (host)
+                for (int q = wave; q < a.nq; q += 4) {
+                    u64 x[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int idx = e * 64 + lane;
+                        x[e] = idx < M ? __hip_atomic_load(a.bmax + (size_t)q * M + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                       : 0ull;
+                    }
+                    int valid = 0;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) valid += __popcll(__ballot(x[e] != 0ull));
+                    const u32 T = valid >= a.k ? wave_kth_key<16>(x, a.k) : 0u;
+                    if (lane == 0)
+                        __hip_atomic_store(a.sync + 2 + q, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                wait_vmcnt<0>();
+                wg_barrier();
+                if (tid == 0) __hip_atomic_store(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (!got_global) {
+            // thresholds there yet?  (one sc1 poll per tile boundary; nobody waits)
+            if (wave == 0) {
+                const u32 r = __hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (r && lane < a.nq) {
+                    const u32 t = __hip_atomic_load(a.sync + 2 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sThr[lane] = max(sThr[lane], t);
+                }
+                if (lane == 0) sFlag[1] = r;
+            }
+            wg_barrier();
+            const bool ready = sFlag[1] != 0u;
+            got_global = ready;
+            if (!have_thr && (ready || nheld == ST_HOLD || tile + 1 == t1)) {
+                // flush the held tiles through the filter (without thresholds: one tile at a time, compacting)
+#pragma unroll
+                for (int h = 0; h < ST_HOLD; ++h) {
+                    if (h < nheld) {
+                        append_tile(held[h], held_tile0 + h);
+                        wg_barrier();
+                        if (__builtin_amdgcn_readfirstlane(sFlag[0])) compact_pass(false);
+                    }
+                }
+                nheld = 0;
+                have_thr = true;
+            } else if (have_thr && __builtin_amdgcn_readfirstlane(sFlag[0])) {
+                compact_pass(false);
+            }
+        } else if (__builtin_amdgcn_readfirstlane(sFlag[0])) {
+            compact_pass(false);
+        }
+    }
+    compact_pass(true);
+    if (tid < NQP) a.cnt[(size_t)strip * NQP + tid] = min(sCnt[tid], (u32)CAP);
+}
 
 struct Scan16Args {
     const char* X;      // corpus, bf16, tile-blocked plane of cap_rows x ldk elements (plane_index)
@@ -1628,11 +1905,18 @@ __global__ __launch_bounds__(NT) void merge_kernel(MergeArgs a) {
                 }
                 se = lo2;
             }
-            for (int t = sb + wave; t < se; t += NWV) {
-                const int o0 = sOff[t], c = sOff[t + 1] - o0;
-                const u64* src = a.in + ((size_t)(s0 + t) * a.nq_pad + q) * a.cap_in;
-                u64* dst = l + n + (o0 - sOff[sb]);
-                for (int i = lane; i < c; i += 64) dst[i] = src[i];
+            {
+                // flat gather: entry idx of the round belongs to the strip t with sOff[t] <= base + idx < sOff[t + 1];
+                // every thread's loads are in flight together (a strip-by-strip copy is a chain of dependent loads)
+                const int base = sOff[sb], tot = sOff[se] - base;
+                for (int idx = tid; idx < tot; idx += NT) {
+                    int lo2 = sb, hi2 = se - 1;
+                    while (lo2 < hi2) {
+                        const int mid = (lo2 + hi2 + 1) >> 1;
+                        if (sOff[mid] <= base + idx) lo2 = mid; else hi2 = mid - 1;
+                    }
+                    l[n + idx] = a.in[((size_t)(s0 + lo2) * a.nq_pad + q) * a.cap_in + (base + idx - sOff[lo2])];
+                }
             }
             n += sOff[se] - sOff[sb];
             sb = se;
@@ -1871,6 +2155,20 @@ void launch_stream(const StreamArgs& a, int grid, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
 }
 
+template <int EPL, int NSTAGE>
+void launch_stream16(const StreamArgs& a, int grid, hipStream_t st) {
+    auto kern = stream16_kernel<EPL, NSTAGE>;
+    const int lds = 4 * NSTAGE * (64 * 128 + 2 * 1024) + 67 * (int)sizeof(u32);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+}
+
 struct Scan16Cfg {
     int cap;
     void (*launch)(const Scan16Args&, int grid, hipStream_t);
@@ -2088,16 +2386,17 @@ bool g_scratch_sync_dirty[64] = {};
 
 // at most 32 queries, k <= 128: the stream kernel + one merge (no sample pass, no pad kernel for aligned rows)
 int search_chunk_stream(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st,
-                        Scratch* sc) {
+                        Scratch* sc, const void* q16_plane = nullptr) {
     constexpr int EPL = 8, CAP = EPL * 64;
-    const int G = nq <= 4 ? 1 : nq <= 8 ? 2 : nq <= 16 ? 4 : 8;
+    const bool b16 = ix->dtype == OTTER_BF16;       // stream16_kernel: q16_plane = the queries' bf16 plane (16 columns)
+    const int G = b16 ? 4 : nq <= 4 ? 1 : nq <= 8 ? 2 : nq <= 16 ? 4 : 8;
     const int nqp = 4 * G;
     const int total_tiles = (int)((ix->n + ST_BM - 1) / ST_BM);
     int strips = std::min(std::min(ix->ncu, NA_MAX_STRIPS), total_tiles);
     strips = std::max(strips, 1);
     int rc;
     void *w_qpad = nullptr, *w_cand, *w_cnt, *w_bmax, *w_sync;
-    const bool q_in_place = ix->ld == ix->d && ((uintptr_t)qd & 15) == 0;
+    const bool q_in_place = b16 || (ix->ld == ix->d && ((uintptr_t)qd & 15) == 0);
     if (!q_in_place && (rc = sc->get(ix->qpad, (size_t)nqp * ix->ld * sizeof(float), &w_qpad))) return rc;
     if ((rc = sc->get(ix->cand, (size_t)strips * nqp * CAP * sizeof(u64), &w_cand))) return rc;
     if ((rc = sc->get(ix->cnt, (size_t)strips * nqp * sizeof(u32), &w_cnt))) return rc;
@@ -2115,8 +2414,8 @@ int search_chunk_stream(otter_index* ix, const float* qd, long long nq, int k, f
                            (long long)nqp, ix->d, ix->ld);
     }
     StreamArgs sa;
-    sa.X = ix->x;
-    sa.Q = q_in_place ? qd : (const float*)w_qpad;
+    sa.X = b16 ? (const float*)ix->x16 : ix->x;
+    sa.Q = b16 ? (const float*)q16_plane : q_in_place ? qd : (const float*)w_qpad;
     sa.q_rows = q_in_place ? (int)nq : nqp;
     sa.cand = (u64*)w_cand;
     sa.cnt = (u32*)w_cnt;
@@ -2144,7 +2443,8 @@ int search_chunk_stream(otter_index* ix, const float* qd, long long nq, int k, f
         OTTER_HIP_TRY(hipEventRecord(ev.first, st));
     }
     // (ring depth by LDS: 4 waves x slots x (8 KiB + queries))
-    if (G == 1) launch_stream<1, EPL, 32, 4>(sa, strips, st);
+    if (b16) launch_stream16<EPL, 3>(sa, strips, st);
+    else if (G == 1) launch_stream<1, EPL, 32, 4>(sa, strips, st);
     else if (G == 2) launch_stream<2, EPL, 32, 4>(sa, strips, st);
     else if (G == 4) launch_stream<4, EPL, 32, 3>(sa, strips, st);
     else launch_stream<8, EPL, 32, 3>(sa, strips, st);
@@ -2454,6 +2754,11 @@ int search_chunk_bf16(otter_index* ix, const float* qd, long long nq, int k, flo
         hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256),
                            0, st, qd, (unsigned short*)ix->qs.p, nq, nq_pad, ix->d, ix->ld, 0ll);
         OTTER_HIP_TRY(hipGetLastError());
+    }
+    static const char* no_stream = getenv("OTTER_NO_STREAM");
+    if (nq <= 16 && k <= 128 && !no_stream) {
+        Scratch own;
+        return search_chunk_stream(ix, qd, nq, k, D, I, st, &own, ix->qs.p);
     }
     return scan16_and_merge<0>(ix, ix->x16, ix->ld, nq, k, D, I, st);
 }

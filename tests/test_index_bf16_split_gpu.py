@@ -130,6 +130,25 @@ def test_bf16_index_against_rounded_operands(n, d, nq, k):
     assert rec >= 0.9, rec
 
 
+@pytest.mark.parametrize("n,d,k", [(300000, 768, 100), (70000, 100, 128), (999, 768, 10)])
+def test_bf16_small_batches_share_the_large_batch_arithmetic(n, d, k):
+    """<= 16 queries take stream16_kernel, larger batches scan16_kernel<0>: same instruction, same operand
+    roles, same k order -> the same scores and rows, bit for bit, whatever the batch size."""
+    from otter_amd.index import IndexFlatIP
+    xb, q = _mk(n, d, 40, seed=n + d + k)
+    ix = IndexFlatIP(d, dtype="bf16")
+    ix.add(xb)
+    Dl, Il = ix.search(q, k)                      # 40 queries: scan16 path
+    for lo, hi in [(0, 1), (1, 4), (4, 20), (20, 33), (33, 40)]:
+        if hi - lo > 16:
+            continue
+        D, I = ix.search(q[lo:hi], k)
+        np.testing.assert_array_equal(I, Il[lo:hi])
+        np.testing.assert_array_equal(D.view(np.int32), Dl[lo:hi].view(np.int32))
+    flat_ip.check_topk(_bf16_round(xb), _bf16_round(q[:7]), *ix.search(q[:7], k), k, rtol=1e-5)
+    ix.close()
+
+
 def test_bf16_index_incremental_device_add_and_limits():
     from otter_amd.index import IndexFlatIP
     xb, q = _mk(20000, 768, 16, seed=2)

@@ -49,6 +49,18 @@ CASES = [
     (540000, 128, 40, 200),
     (530000, 64, 1, 1),
     (530000, 64, 64, 256),
+    # stream kernel (<= 16 queries, k <= 128): every query-group width, ragged tiles, threshold exchange on
+    # (>= 2 tiles per workgroup) and off, d = 2304 and a d that needs the padded copy of the queries
+    (300000, 768, 2, 128),
+    (300001, 768, 3, 100),
+    (200000, 2304, 9, 100),
+    (140000, 100, 16, 37),
+    (1000, 768, 13, 128),
+    (257, 64, 4, 100),
+    # <= 64 queries with k > 256 on a corpus large enough for the sample pass: n >= 12 * 64 k
+    (800000, 64, 40, 1000),
+    (1600000, 64, 3, 2048),
+    (900000, 64, 20, 1000),
 ]
 
 
@@ -61,6 +73,50 @@ def test_search_matches_oracle(n, d, nq, k):
     np.testing.assert_array_equal(I, Ir)
     np.testing.assert_array_equal(D.view(np.uint32), Dr.view(np.uint32))
     flat_ip.check_topk(xb, q, D, I, k, rtol=1e-5)
+
+
+def test_stream_kernel_survives_a_threshold_that_passes_everything():
+    """All rows equal: every block maximum ties the threshold, so every row of every tile is accepted and the
+    candidate buffers compact after each tile; ids decide (0 .. k-1)."""
+    from otter_amd.index import IndexFlatIP
+    rng = np.random.RandomState(3)
+    row = rng.randn(128).astype(np.float32)
+    xb = np.tile(row, (300000, 1))
+    q = rng.randn(5, 128).astype(np.float32)
+    ix = IndexFlatIP(128)
+    ix.add(xb)
+    D, I = ix.search(q, 100)
+    assert (I == np.arange(100)[None, :]).all()
+    assert (D == D[:, :1]).all()
+    # the same corpus with one better row far away: it must come first
+    xb[299999] = q[2] * 3.0
+    ix.reset()
+    ix.add(xb)
+    D, I = ix.search(q, 100)
+    assert I[2, 0] == 299999 and (I[2, 1:] == np.arange(99)).all()
+    ix.close()
+
+
+def test_stream_kernel_repeated_calls_leave_clean_counters():
+    """The exchange counters are zeroed by the merge of the previous search: results must not depend on history
+    (different batch sizes and k alternate on one index)."""
+    from otter_amd.index import IndexFlatIP
+    xb, q = _mk(280000, 256, 16, seed=9)
+    ix = IndexFlatIP(256)
+    ix.add(xb)
+    ref = {}
+    for nq, k in [(1, 100), (16, 10), (5, 128), (1, 1), (9, 64), (1, 100), (16, 10)]:
+        D, I = ix.search(q[:nq], k)
+        key = (nq, k)
+        if key not in ref:
+            Dr, Ir = flat_ip.search_c(xb, q[:nq], k, mode=flat_ip.MODE_GPU_ORDER)
+            np.testing.assert_array_equal(I, Ir)
+            np.testing.assert_array_equal(D, Dr)
+            ref[key] = (D, I)
+        else:
+            np.testing.assert_array_equal(I, ref[key][1])
+            np.testing.assert_array_equal(D, ref[key][0])
+    ix.close()
 
 
 def test_incremental_add_and_reset():
