@@ -78,3 +78,126 @@ def test_config1_full_size_properties():
     Dm, Im = merge_topk(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), device=0)
     assert torch.equal(Im, I)
     assert torch.equal(Dm.view(torch.int32), D.view(torch.int32))
+
+
+@pytest.fixture(scope="module")
+def corpus_1m():
+    xb = _rows(N, 1234)
+    yield xb
+    del xb
+    torch.cuda.empty_cache()
+
+
+def test_batch_size_ladder_is_one_result(corpus_1m):
+    """configs[2]'s query-batch range on one 1M x 768 fp32 shard: whatever regime serves a batch (stream kernel up to
+    16 queries, 32x32x2 kernel up to 32, coarse bf16 pass + exact re-scoring from 33 on), the rows and scores of a
+    query are the same bits.  Reference = the queries searched 16 at a time (stream kernel); independent arbiter =
+    the oracle's float64 rule on a sample."""
+    from otter_amd.index import IndexFlatIP
+    xb = corpus_1m
+    q = _rows(4096, 97)
+    ix = IndexFlatIP(DIM)
+    ix.add(xb)
+    Dr = torch.empty((4096, K), dtype=torch.float32, device="cuda")
+    Ir = torch.empty((4096, K), dtype=torch.int64, device="cuda")
+    for lo in range(0, 4096, 16):
+        Dr[lo:lo + 16], Ir[lo:lo + 16] = ix.search(q[lo:lo + 16].contiguous(), K)
+    for nq in (1, 8, 17, 32, 33, 64, 256, 4096):
+        D, I = ix.search(q[:nq].contiguous(), K)
+        assert torch.equal(I, Ir[:nq]), "batch of %d: ids differ from the 16-query calls" % nq
+        assert torch.equal(D.view(torch.int32), Dr[:nq].view(torch.int32)), "batch of %d: scores differ" % nq
+    assert ix.last_fallback == 0
+    ix.close()
+    sample = [0, 5, 4095]
+    nd = flat_ip.check_topk(xb.cpu().numpy(), q[sample].cpu().numpy(), Dr[sample].cpu().numpy(), Ir[sample].cpu().numpy(),
+                            K, rtol=1e-5)
+    assert nd <= 2
+
+
+def test_eight_shards_on_one_device_merge_to_the_unsharded_result(corpus_1m):
+    """configs[2]'s row sharding (8 shards with id_base) on one device: per-shard top-k + the GPU merge of the
+    multi-GPU path = the unsharded index's (D, I), bit for bit, for a small and a large batch."""
+    from otter_amd.index import IndexFlatIP, merge_topk
+    xb = corpus_1m
+    q = _rows(300, 98)
+    whole = IndexFlatIP(DIM)
+    whole.add(xb)
+    per = N // 8
+    shards = []
+    for r in range(8):
+        sh = IndexFlatIP(DIM, id_base=r * per)
+        sh.add(xb[r * per:(r + 1) * per])
+        shards.append(sh)
+    for nq in (1, 300):
+        qq = q[:nq].contiguous()
+        D, I = whole.search(qq, K)
+        parts = [sh.search(qq, K) for sh in shards]
+        Dm, Im = merge_topk(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), device=0)
+        assert torch.equal(Im, I) and torch.equal(Dm.view(torch.int32), D.view(torch.int32))
+    for sh in shards:
+        sh.close()
+    whole.close()
+
+
+def test_config5_shard_bf16_top1000_properties():
+    """BASELINE.json configs[4], one GPU's shard at full size: 12.5M x 768 rows stored as bf16 (19.2 GB), 16,384
+    queries, k = 1000.  Properties that do not need an oracle run over 12.5M rows: order, uniqueness, range; scores
+    = float64 dot products of the ROUNDED operands (the bf16 index's definition) within 1e-5 |q| max|x|;
+    completeness on a query sample against torch's matmul over all rows; recall against an fp32 index on a
+    1M-row slice (reported separately, as north_star asks for bf16 paths)."""
+    from otter_amd.index import IndexFlatIP
+    n5, nq5, k5 = 12500000, 16384, 1000
+    ix = IndexFlatIP(DIM, dtype="bf16")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(55)
+    slab = 500000
+    for lo in range(0, n5, slab):
+        ix.add(torch.randn((slab, DIM), generator=g, device="cuda"))
+    assert ix.ntotal == n5
+    q = _rows(nq5, 56)
+    D, I = ix.search(q, k5)
+    assert D.shape == (nq5, k5)
+    assert bool((D[:, 1:] <= D[:, :-1]).all())
+    assert bool(((I >= 0) & (I < n5)).all())
+    for lo in range(0, nq5, 2048):                                   # uniqueness, 2048 queries at a time
+        srt = torch.sort(I[lo:lo + 2048], dim=1).values
+        assert bool((srt[:, 1:] != srt[:, :-1]).all())
+        del srt
+    # scores of a query sample against float64 products of the rounded operands + completeness over ALL rows
+    sample = torch.tensor([0, 1, 4097, 9000, nq5 - 1], device="cuda")
+    qs = q[sample].to(torch.bfloat16).double()
+    kth = D[sample, k5 - 1].double()
+    tol = 1e-5 * qs.pow(2).sum(1).sqrt() * float((DIM ** 0.5) * 1.6)   # |x| <= ~1.6 sqrt(d) for gaussian rows
+    above = torch.zeros(len(sample), dtype=torch.int64, device="cuda")
+    g.manual_seed(55)
+    found = torch.zeros((len(sample), k5), dtype=torch.bool, device="cuda")
+    for lo in range(0, n5, slab):
+        xs = torch.randn((slab, DIM), generator=g, device="cuda").to(torch.bfloat16).double()
+        S = qs @ xs.t()                                                # [5, slab] float64
+        above += (S > (kth + 2 * tol)[:, None]).sum(1)
+        ids = I[sample] - lo
+        inside = (ids >= 0) & (ids < slab)
+        got = torch.gather(S, 1, ids.clamp(0, slab - 1))
+        ok = (got - D[sample].double()).abs() <= tol[:, None]
+        assert bool((ok | ~inside).all()), "a returned score is not the float64 product of the rounded operands"
+        found |= inside
+        del xs, S
+    assert bool(found.all())
+    assert bool((above < k5).all()), "a row outside the result outranks the k-th returned score"
+    # recall@1000 against the fp32 ranking of the unrounded first 1M rows (both indexes over that slice)
+    g.manual_seed(55)
+    x1 = torch.cat([torch.randn((slab, DIM), generator=g, device="cuda") for _ in range(2)])
+    ix.close()
+    a16 = IndexFlatIP(DIM, dtype="bf16")
+    a16.add(x1)
+    a32 = IndexFlatIP(DIM)
+    a32.add(x1)
+    _, I16 = a16.search(q[:256].contiguous(), k5)
+    _, I32 = a32.search(q[:256].contiguous(), k5)
+    hit = 0
+    for r in range(256):
+        hit += len(set(I16[r].tolist()) & set(I32[r].tolist()))
+    recall = hit / (256.0 * k5)
+    assert recall >= 0.97, recall
+    a16.close()
+    a32.close()
