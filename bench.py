@@ -291,7 +291,7 @@ def small_batch_leg(index, q, k, n, d):
     """The reference's real call pattern (nq = 1 per call, scripts/eval_ottqa_retrieval.py:126-129) and the
     rest of the HBM-bound regime: one corpus read per search, N*d*4 algorithmic bytes."""
     out = []
-    for nq in (1, 8, 32):
+    for nq in (1, 8, 16, 32):
         scan_ms, wall_ms = timed_search(index, q[:nq].contiguous(), k, 30, 5)
         byts = float(n) * d * 4
         out.append({"nq": nq, "scan_ms": scan_ms, "wall_ms": wall_ms, "queries_per_s": nq / (wall_ms * 1e-3),
@@ -299,8 +299,11 @@ def small_batch_leg(index, q, k, n, d):
                     "hbm_frac_scan": byts / (scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                     "hbm_frac_wall": byts / (wall_ms * 1e-3) / 1e9 / PEAK_HBM_GBS})
     return {"bound": "hbm", "peak_GBps": PEAK_HBM_GBS, "algorithmic_bytes_per_search": float(n) * d * 4,
+            "kernel": "stream_kernel (<= 16 queries: lane = row, per-wave LDS-DMA rings with non-temporal loads, "
+                      "v_mfma_f32_4x4x1 fma chain, in-kernel threshold exchange) + one merge_kernel launch; 17 ... 32 "
+                      "queries: scan_kernel (32x32x2 tile) with a sample pass",
             "note": "scan_ms = HIP events around every kernel that reads corpus rows; wall_ms = host clock per "
-                    "search() call incl. every side kernel", "points": out}
+                    "search() call incl. every side kernel and the launch gaps", "points": out}
 
 
 def free_port():
@@ -491,6 +494,23 @@ def main():
         for _ in range(reps):
             index.search(qh, k)
         pdt = (time.perf_counter() - t0) / reps
+        # the same regime on a bf16-storage index (BASELINE.json configs[4]'s storage type; reported separately)
+        xb16 = gen_rows(n, d, 1234 + rank, dev)
+        ix16 = IndexFlatIP(d, device=local_rank, dtype="bf16")
+        ix16.add(xb16)
+        del xb16
+        torch.cuda.empty_cache()
+        pts = []
+        for nq1 in (1, 16):
+            s_ms, w_ms = timed_search(ix16, q[:nq1].contiguous(), k, 30, 5)
+            pts.append({"nq": nq1, "scan_ms": s_ms, "wall_ms": w_ms, "GBps_wall": float(n) * d * 2 / (w_ms * 1e-3) / 1e9,
+                        "hbm_frac_scan": float(n) * d * 2 / (s_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                        "hbm_frac_wall": float(n) * d * 2 / (w_ms * 1e-3) / 1e9 / PEAK_HBM_GBS})
+        extra["small_batches_bf16_index"] = {"bound": "hbm", "algorithmic_bytes_per_search": float(n) * d * 2,
+                                             "kernel": "stream16_kernel (v_mfma_f32_16x16x32_bf16)", "points": pts}
+        ix16.close()
+        del ix16
+        torch.cuda.empty_cache()
         extra["pcie"] = {"value": nq / pdt, "unit": "queries/s", "ms_per_step": pdt * 1e3,
                          "note": "same search with pageable host numpy buffers: H2D of %d x %d fp32 queries + D2H of "
                                  "(D, I) inside the call; never `value`" % (nq, d)}

@@ -2361,11 +2361,14 @@ int run_merge(otter_index* ix, const u64* in, const u32* in_cnt, int cap_in, int
     static const char* mv = getenv("OTTER_MERGE_VARIANT");      // A/B switch for tuning runs
     if (mv && mv[0] == 'a') return launch_merge<1024, MAX_SELECT>(ix->device, ma, nq, st);
     if (mv && mv[0] == 'b') return launch_merge<512, MAX_SELECT>(ix->device, ma, nq, st);
-    if ((long long)S_in * take + k <= 1024) return launch_merge<256, 1024>(ix->device, ma, nq, st);
+    const long long all_in = (long long)S_in * take + k;
+    if (all_in <= 1024) return launch_merge<256, 1024>(ix->device, ma, nq, st);
     if (mv && mv[0] == 'c') return launch_merge<512, 4096>(ix->device, ma, nq, st);
     // few queries: latency counts, 16 waves gather the strips in parallel; many queries: throughput counts, small
-    // workgroups share a CU (measured: 1 ... 256 queries 1024 threads, 2214 queries 256 threads)
+    // workgroups share a CU (measured: 1 ... 256 queries 1024 threads, 2214 queries 256 threads); a pool that
+    // takes every strip at once needs one select round
     if (nq < 1024 && k + take <= MAX_SELECT) return launch_merge<1024, MAX_SELECT>(ix->device, ma, nq, st);
+    if (all_in > 4096 && all_in <= MAX_SELECT && !(mv && mv[0] == 'd')) return launch_merge<512, MAX_SELECT>(ix->device, ma, nq, st);
     if (k + take <= 4096) return launch_merge<256, 4096>(ix->device, ma, nq, st);
     if (k + take > MAX_SELECT)
         return set_err(OTTER_EINVAL, "merge: k=%d + %d entries per strip exceed the %d-entry pool", k, take, MAX_SELECT);

@@ -29,6 +29,7 @@ class _PipeSlot:
         self.rows = 0
         self.dim = 0
         self.busy = False
+        self.ran = False         # a forward has read this slot's device inputs (ev_fwd is recorded)
         if use_cuda:
             self.ev_h2d = torch.cuda.Event()
             self.ev_fwd = torch.cuda.Event()
@@ -48,6 +49,8 @@ class _PipeSlot:
         """Host batch dict -> device batch dict; the copies are enqueued on copy_stream."""
         if self.use_cuda:
             self.ev_h2d.synchronize()     # the pinned staging of this slot's previous batch has been read
+            if self.ran:                  # ... and its device copies by the forward that used them (device-side wait)
+                copy_stream.wait_event(self.ev_fwd)
         out = {}
         for name, t in batch.items():
             if not torch.is_tensor(t):
@@ -76,12 +79,14 @@ class _PipeSlot:
         self.rows, self.dim = int(embed.shape[0]), int(embed.shape[1])
         self.out_dev = embed
         self.busy = True
+        if self.use_cuda and embed.is_cuda:
+            self.ev_fwd.record(torch.cuda.current_stream(embed.device))
+            self.ran = True
         if not (to_cpu and self.use_cuda and embed.is_cuda):
             return
         n = embed.numel()
         if self.out_pin is None or self.out_pin.numel() < n:
             self.out_pin = torch.empty((n,), dtype=torch.float32, pin_memory=True)
-        self.ev_fwd.record(torch.cuda.current_stream(embed.device))
         with torch.cuda.stream(down_stream):
             down_stream.wait_event(self.ev_fwd)
             self.out_pin[:n].view(self.rows, self.dim).copy_(embed, non_blocking=True)
