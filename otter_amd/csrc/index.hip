@@ -846,6 +846,289 @@ __global__ __launch_bounds__(256) void stream_kernel(StreamArgs a) {
 // (per-query threshold in LDS, candidate buffers, wave radix compaction).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// ------------------------------------------------------------------ stream kernel, 17 ... 32 queries
+// stream_kernel's structure (per-wave rings, non-temporal corpus loads, threshold exchange, no sample pass) with
+// scan_kernel's v_mfma_f32_32x32x2_f32 fragments: a wave's 64 rows are two 32-row blocks against all 32 query
+// columns; from 17 queries on that tile is cheaper than 4x4x1 products (same fma chain either way).
+template <int EPL, int ST_NSTAGE>
+__global__ __launch_bounds__(256) void stream32_kernel(StreamArgs a) {
+    constexpr int NQP = 32;                    // query columns of one 32x32x2 block
+    constexpr int G = 8;                       // (query rows of a stage = 4 G, as in stream_kernel)
+    constexpr int RB = 2;                      // 32-row blocks of a wave's 64 rows
+    constexpr int ST_BK = 32;
+    constexpr int ST_HOLD = 3;                 // tiles whose scores wait in registers for the thresholds (32 per tile)
+    constexpr int CAP = EPL * 64;
+    constexpr int QI = st_qinstr(G, ST_BK), ST_SLOT = st_slot(G, ST_BK), ST_IPS = st_ips(G, ST_BK);
+    constexpr int CH = ST_BK / 4;              // 16-byte chunks per row of a stage
+    constexpr int RPI = 64 / CH;               // rows per LDS-DMA instruction
+    constexpr int ROWB = ST_BK * 4;            // bytes per row of a stage
+    static_assert(ST_BK == 32 || ST_BK == 64, "stage depth");
+    static_assert(CAP - ST_BM >= 128, "candidate buffer too small");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32* sCnt = reinterpret_cast<u32*>(smem + 4 * ST_NSTAGE * ST_SLOT);
+    u32* sThr = sCnt + 32;
+    u32* sFlag = sThr + 32;       // [0] compaction wanted, [1] thresholds ready, [2] this workgroup selects
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int strip = blockIdx.x;
+    const int t0 = (int)(((long long)strip * a.total_tiles) / a.strips);
+    const int t1 = (int)(((long long)(strip + 1) * a.total_tiles) / a.strips);
+    const int KS = a.ld / ST_BK;
+    if (tid < 32) {
+        sCnt[tid] = 0;
+        sThr[tid] = 0u;            // accept everything (key >= 0) until a threshold is known
+    }
+    if (tid < 3) sFlag[tid] = 0;
+    u64* candBase = a.cand + (size_t)strip * NQP * CAP;
+
+    // ---- producer: this wave's 64 rows x BK floats (1 KiB per instruction) + the queries' BK floats
+    // LDS image: [row][CH chunks of 16 B], chunk position p of row r holds global chunk p ^ swz(r), swz chosen so
+    // that the rows one ds_read_b128 lane group touches fall on distinct 16-byte slots of the 256-byte bank row
+    auto swz = [](int r) { return CH == 16 ? (r & 15) : ((r >> 1) & 7); };
+    const u32 lds0 = (u32)(uintptr_t)(AS3 char*)smem + (u32)wave * (ST_NSTAGE * ST_SLOT);
+    u32 voffA[CH], voffQ[QI];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int r = RPI * i + lane / CH;
+        voffA[i] = ((u32)(wave * 64 + r) * (u32)a.ld + (u32)(((lane % CH) ^ swz(r)) << 2)) * 4u;
+    }
+#pragma unroll
+    for (int i = 0; i < QI; ++i) {
+        const int r = RPI * i + lane / CH;       // a row past the batch reads its last row (never accepted)
+        voffQ[i] = ((u32)min(r, max(a.q_rows - 1, 0)) * (u32)a.ld + (u32)(((lane % CH) ^ swz(r)) << 2)) * 4u;   // (swizzled like the rows)
+    }
+    const long long total_stages = (long long)(t1 - t0) * KS;
+    int it_tile = t0, it_ks = 0;
+    long long it_f = 0;
+    auto issue_stage = [&]() {
+        if (it_f < total_stages) {
+            const float* gA = a.X + ((size_t)it_tile * ST_BM * a.ld + (size_t)it_ks * ST_BK);
+            const float* gQ = a.Q + (size_t)it_ks * ST_BK;
+            const u32 l = lds0 + (u32)(it_f % ST_NSTAGE) * ST_SLOT;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) dma16s_stream(gA, voffA[i], l + i * 1024);
+#pragma unroll
+            for (int i = 0; i < QI; ++i) dma16s(gQ, voffQ[i], l + CH * 1024 + i * 1024);
+            ++it_f;
+            if (++it_ks == KS) { it_ks = 0; ++it_tile; }
+        }
+    };
+
+    // ---- candidate path.  Lane l (query l & 31, half h = l >> 5) holds, per 32-row block b, the scores of rows
+    // 32 b + (r & 3) + 8 (r >> 2) + 4 h (r = 0..15) of this wave's 64
+    const int l31 = lane & 31, hh = lane >> 5;
+    auto append_tile = [&](const f32x16 (&sc)[RB], int tile) {
+        const int q = l31;
+        const u32 thr = sThr[q];
+        const float thrf = key2f(thr);
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            // after warm-up almost nothing passes: test the block's maximum first
+            float mx = fmaxf(sc[b][0], sc[b][1]);
+#pragma unroll
+            for (int r = 2; r < 16; ++r) mx = fmaxf(mx, sc[b][r]);
+            if (!(thr == 0u || mx >= thrf || mx != mx)) continue;
+            const long long row0 = (long long)tile * ST_BM + wave * 64 + 32 * b + 4 * hh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long row = row0 + (r & 3) + 8 * (r >> 2);
+                const u32 key = f2key(sc[b][r]);
+                if (q < a.nq && key >= thr && row < a.n) {
+                    const u32 pos = atomicAdd(&sCnt[q], 1u);
+                    if (pos < (u32)CAP) candBase[(u32)q * (u32)CAP + pos] = ((u64)key << 32) | (u64)(0xFFFFFFFFu - (u32)row);
+                    if (pos + 1 > (u32)(CAP - ST_BM)) sFlag[0] = 1;
+                }
+            }
+        }
+    };
+    auto compact_pass = [&](bool final_pass) {      // workgroup-wide; every wave calls it at the same point
+        wait_vmcnt<0>();
+        wg_barrier();
+        for (int q = wave; q < NQP; q += 4) {
+            const int n = (int)min(sCnt[q], (u32)CAP);
+            const bool need = final_pass ? (n > a.k) : (n > CAP - ST_BM);
+            if (need) {
+                const u64 T = wave_compact<EPL>(candBase + (size_t)q * CAP, n, a.k, lane);
+                if (lane == 0) {
+                    sCnt[q] = (u32)a.k;
+                    sThr[q] = max(sThr[q], (u32)(T >> 32));
+                }
+            }
+        }
+        if (tid == 0) sFlag[0] = 0;
+        wait_vmcnt<0>();
+        wg_barrier();
+    };
+
+    f32x16 acc[RB];
+    f32x16 held[ST_HOLD][RB];
+    int nheld = 0, held_tile0 = t0;
+    bool have_thr = a.seed == 0;     // no exchange: thresholds are learned locally from the start
+    bool got_global = a.seed == 0;   // the exchanged thresholds have been taken over (or there are none to wait for)
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
+
+#pragma unroll
+    for (int s2 = 0; s2 < ST_NSTAGE - 1; ++s2) issue_stage();
+
+    const u32 rowoff = (u32)l31 * (u32)ROWB;
+    const u32 rswz = (u32)swz(l31);              // (swz(32 b + l31) == swz(l31))
+    long long f = 0;
+    for (int tile = t0; tile < t1; ++tile) {
+        for (int ks = 0; ks < KS; ++ks, ++f) {
+            // stage f (this wave's own loads) has landed once at most NSTAGE-2 younger stages are outstanding
+            if (total_stages - 1 - f >= ST_NSTAGE - 2) wait_vmcnt<(ST_NSTAGE - 2) * ST_IPS>();
+            else wait_vmcnt<0>();
+            // the slot of stage f-1 was read by this wave only, and those reads have returned (their values fed
+            // the products above): refill it with stage f + NSTAGE - 1
+            wait_lgkm0();
+            issue_stage();
+            const char* sA = smem + wave * (ST_NSTAGE * ST_SLOT) + (int)(f % ST_NSTAGE) * ST_SLOT;
+            const char* sQ = sA + CH * 1024;
+            // scan_kernel's fragments: 16 bytes per lane = four k-steps (k = 8 j + 4 h + t), same fma chain
+#pragma unroll
+            for (int j = 0; j < ST_BK / 8; ++j) {
+                const u32 co = ((u32)(2 * j + hh) ^ rswz) << 4;
+                const float4 qf = *reinterpret_cast<const float4*>(sQ + rowoff + co);
+#pragma unroll
+                for (int b = 0; b < RB; ++b) {
+                    const float4 xf = *reinterpret_cast<const float4*>(sA + b * 32 * ROWB + rowoff + co);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xf.x, qf.x, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xf.y, qf.y, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xf.z, qf.z, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xf.w, qf.w, acc[b], 0, 0, 0);
+                }
+            }
+        }
+        // ---- end of a tile
+        if (have_thr) {
+            append_tile(acc, tile);
+        } else {
+            if (nheld == 0) held_tile0 = tile;
+#pragma unroll
+            for (int h = 0; h < ST_HOLD; ++h)
+                if (h == nheld)
+#pragma unroll
+                    for (int b = 0; b < RB; ++b) held[h][b] = acc[b];
+            ++nheld;
+        }
+        if (a.seed && tile == t0) {
+            // publish the best row of this wave's first tile, per query (composites; 0 = no valid row)
+            {
+                const int q = l31;
+                u64 c = 0ull;
+#pragma unroll
+                for (int b = 0; b < RB; ++b) {
+                    const long long row0 = (long long)tile * ST_BM + wave * 64 + 32 * b + 4 * hh;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const long long row = row0 + (r & 3) + 8 * (r >> 2);
+                        const u64 v = (q < a.nq && row < a.n)
+                                          ? (((u64)f2key(acc[b][r]) << 32) | (u64)(0xFFFFFFFFu - (u32)row)) : 0ull;
+                        c = v > c ? v : c;
+                    }
+                }
+                {
+                    const u64 v = __shfl_xor(c, 32);     // the other half of this query's rows
+                    c = v > c ? v : c;
+                }
+                if (lane < 32 && q < a.nq)
+                    __hip_atomic_store(a.bmax + (size_t)q * (4 * a.strips) + 4 * strip + wave, c, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+            wait_vmcnt<0>();            // this wave's stores have left (once per launch: the ring drains with them)
+        }
+#pragma unroll
+        for (int b = 0; b < RB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
+        wg_barrier();                   // tile boundary: every wave has appended / published
+        if (a.seed && tile == t0) {
+            if (tid == 0) {
+                const u32 old = __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sFlag[2] = (old == (u32)a.strips - 1u) ? 1u : 0u;
+            }
+            wg_barrier();
+            if (sFlag[2]) {
+                // last arrival: every block maximum is published.  Wave w selects for queries w, w + 4, ...
+                const int M = 4 * a.strips;          // <= 1024 (host)
+                for (int q = wave; q < a.nq; q += 4) {
+                    u64 x[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int idx = e * 64 + lane;
+                        x[e] = idx < M ? __hip_atomic_load(a.bmax + (size_t)q * M + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                       : 0ull;
+                    }
+                    int valid = 0;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) valid += __popcll(__ballot(x[e] != 0ull));
+                    const u32 T = valid >= a.k ? wave_kth_key<16>(x, a.k) : 0u;
+                    if (lane == 0)
+                        __hip_atomic_store(a.sync + 2 + q, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                wait_vmcnt<0>();
+                wg_barrier();
+                if (tid == 0) __hip_atomic_store(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (!got_global) {
+            // thresholds there yet?  (one sc1 poll per tile boundary; nobody waits)
+            if (wave == 0) {
+                const u32 r = __hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (r && lane < a.nq) {
+                    const u32 t = __hip_atomic_load(a.sync + 2 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sThr[lane] = max(sThr[lane], t);
+                }
+                if (lane == 0) sFlag[1] = r;
+            }
+            wg_barrier();
+            const bool ready = sFlag[1] != 0u;
+            got_global = ready;
+            if (!have_thr && (ready || nheld == ST_HOLD || tile + 1 == t1)) {
+                // flush the held tiles through the filter (without thresholds: one tile at a time, compacting)
+#pragma unroll
+                for (int h = 0; h < ST_HOLD; ++h) {
+                    if (h < nheld) {
+                        append_tile(held[h], held_tile0 + h);
+                        wg_barrier();
+                        if (__builtin_amdgcn_readfirstlane(sFlag[0])) compact_pass(false);
+                    }
+                }
+                nheld = 0;
+                have_thr = true;
+            } else if (have_thr && __builtin_amdgcn_readfirstlane(sFlag[0])) {
+                compact_pass(false);
+            }
+        } else if (__builtin_amdgcn_readfirstlane(sFlag[0])) {
+            compact_pass(false);
+        }
+    }
+    compact_pass(true);
+    if (tid < NQP) a.cnt[(size_t)strip * NQP + tid] = min(sCnt[tid], (u32)CAP);
+}
+
+// ------------------------------------------------------------------ bf16-MFMA scan
+// Same product, on the bf16 matrix cores (16x the fp32 matrix rate).  Two uses:
+//   MODE 0  corpus stored as bf16 (dtype OTTER_BF16; BASELINE config 5): rows are [ld] bf16,
+//           queries rounded to bf16, score = sum over k of x_k q_k accumulated in fp32.
+//   MODE 1  coarse pass of the exact fp32 search: every fp32 value v is split into
+//           hi = bf16(v), lo = bf16(v - hi) (|v - hi - lo| <= 2^-16 |v|); rows are stored
+//           interleaved per 32 values of k as [hi(32) | lo(32)] (128 B), and the score is
+//           x_hi q_hi + x_hi q_lo + x_lo q_hi (the dropped terms are <= 3 * 2^-16 |x_k q_k| each).
+//           The caller keeps k + margin candidates by this coarse score, re-scores them exactly
+//           (rescore_kernel: the fp32 fma chain of scan_kernel) and proves the margin sufficient
+//           (margin_check_kernel) or falls back to scan_kernel for that query.
+// Structure: the encoder GEMM's persistent ping-pong main loop (gemm_bf16.hip: 8 waves = 2 groups
+// one barrier apart, 256 x 256 tile, K-step of 128 B rows as four 16 KiB half-tiles, LDS-DMA six
+// half-tiles ahead with a counted vmcnt, source-side XOR swizzle, v_mfma_f32_16x16x32_bf16) with
+// the queries on the GEMM's token side (lanes) and the corpus rows on its feature side
+// (accumulator rows), streamed over a strip of corpus tiles, and scan_kernel's epilogue
+// (per-query threshold in LDS, candidate buffers, wave radix compaction).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
 // ------------------------------------------------------------------ stream kernel, bf16 storage (at most 16 queries)
 // stream_kernel's structure on an OTTER_BF16 index: a wave streams its own 64 rows of every 256-row tile, one
 // 64-element K-slab (128 B per row; the planes are tile-blocked, so a wave's rows of a slab are 8 KiB of
@@ -2156,6 +2439,20 @@ void launch_stream(const StreamArgs& a, int grid, hipStream_t st) {
 }
 
 template <int EPL, int NSTAGE>
+void launch_stream32(const StreamArgs& a, int grid, hipStream_t st) {
+    auto kern = stream32_kernel<EPL, NSTAGE>;
+    const int lds = 4 * NSTAGE * st_slot(8, 32) + 67 * (int)sizeof(u32);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+}
+
+template <int EPL, int NSTAGE>
 void launch_stream16(const StreamArgs& a, int grid, hipStream_t st) {
     auto kern = stream16_kernel<EPL, NSTAGE>;
     const int lds = 4 * NSTAGE * (64 * 128 + 2 * 1024) + 67 * (int)sizeof(u32);
@@ -2450,7 +2747,7 @@ int search_chunk_stream(otter_index* ix, const float* qd, long long nq, int k, f
     else if (G == 1) launch_stream<1, EPL, 32, 4>(sa, strips, st);
     else if (G == 2) launch_stream<2, EPL, 32, 4>(sa, strips, st);
     else if (G == 4) launch_stream<4, EPL, 32, 3>(sa, strips, st);
-    else launch_stream<8, EPL, 32, 3>(sa, strips, st);
+    else launch_stream32<EPL, 3>(sa, strips, st);
     OTTER_HIP_TRY(hipGetLastError());
     if (timed) {
         OTTER_HIP_TRY(hipEventRecord(ev.second, st));
@@ -2492,9 +2789,8 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
         }
     }
     static const char* no_stream = getenv("OTTER_NO_STREAM");
-    // (measured, 1M x 768: 1 ... 8 queries 0.51 ms, 16 queries 0.54 ms per search; at 17 ... 32 queries the 4x4x1
-    // products cost more than scan_kernel's 32x32x2 tile: 0.76 against 0.69 ms)
-    if (nq <= 16 && k <= 128 && !no_stream) return search_chunk_stream(ix, qd, nq, k, D, I, st, sc);
+    // (1 ... 16 queries: 4x4x1 products, 17 ... 32: 32x32x2 blocks, both in the stream structure)
+    if (nq <= 32 && k <= 128 && !no_stream) return search_chunk_stream(ix, qd, nq, k, D, I, st, sc);
     ScanCfg cfg;
     int rc = pick_cfg(nq, k, &cfg);
     if (rc) return rc;
