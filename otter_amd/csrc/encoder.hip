@@ -68,7 +68,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 
 template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
-    constexpr int BM = 256, BN = 256, ROWB = 128, CH = 8, RPI = 8, NW = 8, NSTAGE = 2;
+    constexpr int BM = 256, BN = 256, ROWB = 128, CH = 8, RPI = 8, NW = 8;
     constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int A_INSTR = BM / RPI / NW, B_INSTR = BN / RPI / NW, IPS = A_INSTR + B_INSTR;
     constexpr int KE = ROWB / (int)sizeof(T);   // k elements per stage
@@ -354,7 +354,7 @@ __device__ __forceinline__ void dma4s(const void* sbase, u32 voff, u32 lds_dst) 
         : "memory");
 }
 
-__device__ __forceinline__ void wait_vmcnt_upto7(int n) {   // n in {0..7} or an even number <= 14
+__device__ __forceinline__ void wait_vmcnt_upto7(int n) {   // n in {0..7} or an even number <= 16
     switch (n) {
         case 0: wait_vmcnt<0>(); break;
         case 1: wait_vmcnt<1>(); break;
@@ -367,7 +367,9 @@ __device__ __forceinline__ void wait_vmcnt_upto7(int n) {   // n in {0..7} or an
         case 8: wait_vmcnt<8>(); break;
         case 10: wait_vmcnt<10>(); break;
         case 12: wait_vmcnt<12>(); break;
-        default: wait_vmcnt<14>(); break;
+        case 14: wait_vmcnt<14>(); break;
+        case 16: wait_vmcnt<16>(); break;
+        default: wait_vmcnt<14>(); break;   // (anything larger: waiting for more than asked is safe)
     }
 }
 
@@ -392,6 +394,9 @@ __global__ __launch_bounds__(1024 / QB, QB == 2 ? 2 : 4) void attn_full_kernel(A
     const int q0 = wave * 32 * QB;
     const bool active = q0 < Lb;                    // wave-uniform
 
+    // fill: key bias first (the only conditional issue: everything after it is counted the same in every wave)
+    const u32 lds0 = (u32)(uintptr_t)(OTTER_AS3 char*)smem;
+    if (wave < nt) dma4s(a.kbias + (size_t)b * a.Lp + wave * 64, (u32)lane * 4u, lds0 + 2 * nt * 8192 + wave * 256);
     // this lane's two query rows: loads hidden from hipcc (it would drain the DMA queue for them)
     f32x4v qf[QB][4];
 #pragma unroll
@@ -403,9 +408,7 @@ __global__ __launch_bounds__(1024 / QB, QB == 2 ? 2 : 4) void attn_full_kernel(A
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf[qb][j]) : "v"(p) : "memory");
         }
     }
-    // fill: key bias, then K and V tile by tile (wave w moves rows 8w .. 8w+7 of every tile)
-    const u32 lds0 = (u32)(uintptr_t)(OTTER_AS3 char*)smem;
-    if (wave < nt) dma4s(a.kbias + (size_t)b * a.Lp + wave * 64, (u32)lane * 4u, lds0 + 2 * nt * 8192 + wave * 256);
+    // then K and V tile by tile (wave w moves rows 8w .. 8w+7 of every tile)
     {
         // piece p of a tile: p < 8 -> K rows 8p .. 8p+7 (swizzled), else V rows 8(p-8) .. (linear)
         u32 voff[PPW], dst[PPW];
@@ -422,6 +425,13 @@ __global__ __launch_bounds__(1024 / QB, QB == 2 ? 2 : 4) void attn_full_kernel(A
             for (int i = 0; i < PPW; ++i) dma16s(tb, voff[i], dst[i] + t * 8192);
         }
     }
+    // The query rows are older than the PPW * nt pieces just issued: wait for exactly them, here, in straight-line
+    // code, and only then let the compiler see the registers as written.  (Without this the register copies it
+    // places ahead of the tile loop read the destinations before the loads have landed.)
+    wait_vmcnt_upto7(PPW * nt);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+        asm volatile("" : "+v"(qf[qb][0]), "+v"(qf[qb][1]), "+v"(qf[qb][2]), "+v"(qf[qb][3]));
 
     f32x16 o[QB][2];
 #pragma unroll
@@ -437,21 +447,16 @@ __global__ __launch_bounds__(1024 / QB, QB == 2 ? 2 : 4) void attn_full_kernel(A
     const int lswz = (l31 >> 1) & 7;
     const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3, dcol0 = 16 * ((lane >> 4) & 1);
 
-    for (int t = 0; t < nt; ++t) {
-        // tile t (and everything older: Q, bias) has landed for this wave, then for all waves
-        wait_vmcnt_upto7(PPW * (nt - 1 - t));
-        if (t == 0) {
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
-                asm volatile("" : "+v"(qf[qb][0]), "+v"(qf[qb][1]), "+v"(qf[qb][2]), "+v"(qf[qb][3]));
-        }
-        asm volatile("s_barrier" ::: "memory");
-        if (!active) continue;
+    // Optional (-DATTN_STAGGER): the two waves that share a SIMD (w and w + 4) run one phase apart: waves 0-3 do
+    // QK^T, softmax and PV of tile t in interval t; waves 4-7 do softmax and PV of tile t - 1 and then QK^T of tile t,
+    // so one partner's softmax (vector ALU) runs beside the other's products (matrix cores).  Same instructions on the
+    // same data per query: results unchanged.  It measured no faster than running in step (the hardware already
+    // interleaves the two waves of a SIMD), so it is off by default.
+    f32x16 s[QB][2];
+    auto qk = [&](int t) {
         const char* kt = sK + t * 8192;
-        const char* vt = sV + t * 8192;
 
         // S^T = K Q^T: [qb][sub] = 32 keys x 32 queries
-        f32x16 s[QB][2];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
@@ -469,22 +474,12 @@ __global__ __launch_bounds__(1024 / QB, QB == 2 ? 2 : 4) void attn_full_kernel(A
                     s[qb][sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[qb][j]), s[qb][sub], 0, 0, 0);
             }
-        // additive bias of this lane's 32 keys (shared by both query blocks)
-        float4 bv[2][4];
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq)
-                bv[sub][rq] = *reinterpret_cast<const float4*>(sB + t * 64 + sub * 32 + 8 * rq + 4 * h);
-
-        // does this tile hold a masked key (padding)?  wave-uniform; bias values are 0 or -1e30
-        bool lm = false;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq)
-                lm = lm || (bv[sub][rq].x + bv[sub][rq].y + bv[sub][rq].z + bv[sub][rq].w) != 0.0f;
-        const bool masked = __ballot(lm) != 0ull;
+    };
+    auto sm_pv = [&](int t) {
+        const char* vt = sV + t * 8192;
+        // does this tile hold a masked key (padding)?  wave-uniform; bias values are 0 or -1e30.  One bias word per
+        // lane (64 keys, 64 lanes); the lane's own 32 bias values are read only on the masked path
+        const bool masked = __ballot(sB[t * 64 + lane] != 0.0f) != 0ull;
 
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
@@ -495,7 +490,7 @@ __global__ __launch_bounds__(1024 / QB, QB == 2 ? 2 : 4) void attn_full_kernel(A
                 for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float4 bb = bv[sub][r >> 2];
+                        const float4 bb = *reinterpret_cast<const float4*>(sB + t * 64 + sub * 32 + 8 * (r >> 2) + 4 * h);
                         const float bias = (r & 3) == 0 ? bb.x : (r & 3) == 1 ? bb.y : (r & 3) == 2 ? bb.z : bb.w;
                         const float v = fmaf(s[qb][sub][r], scale2, bias);
                         s[qb][sub][r] = v;
@@ -578,14 +573,46 @@ __global__ __launch_bounds__(1024 / QB, QB == 2 ? 2 : 4) void attn_full_kernel(A
                         o[qb][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pb[qb], o[qb][d], 0, 0, 0);
                 }
             }
+    };
+#ifdef ATTN_STAGGER
+    const bool late = QB == 2 && wave >= NW / 2;      // wave-uniform
+#else
+    const bool late = false;   // measured (B = 128, L = 512): 14.06 ms per batch staggered, 13.97 ms in step -- off
+#endif
+    auto tile_landed = [&](int t) {
+        // tile t (and everything older: Q, bias) has landed for this wave, then for all waves
+        wait_vmcnt_upto7(PPW * (nt - 1 - t));
+        asm volatile("s_barrier" ::: "memory");
+    };
+    // (two loops, not one loop with a branch inside: each keeps its own, smaller set of live registers -- this kernel
+    // must not spill: its hidden asynchronous loads land in registers the compiler believes are already written)
+    if (!late) {
+        for (int t = 0; t < nt; ++t) {
+            tile_landed(t);
+            if (!active) continue;
+            qk(t);
+            sm_pv(t);
+        }
+    } else {
+        for (int t = 0; t < nt; ++t) {
+            tile_landed(t);
+            if (!active) continue;
+            if (t > 0) sm_pv(t - 1);
+            qk(t);
+        }
+        if (active && nt > 0) sm_pv(nt - 1);
     }
 
     // normalise and store: lanes l and l + 32 hold one query; after the swap a lane holds 8
     // consecutive head dimensions (16 B): half 0 -> [8 rq, 8 rq + 8), half 1 -> the next 8
     if (active) {
+        // (the lane index is made opaque here so that the store addresses are derived after the loops: computed at
+        // kernel entry they would be spilled around them, and this kernel must not spill)
+        int l31e = l31;
+        asm volatile("" : "+v"(l31e));
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            const int q = q0 + qb * 32 + l31;
+            const int q = q0 + qb * 32 + l31e;
             const float inv = 1.0f / lrun[qb];
             bf16_t* dst = (bf16_t*)a.CTX + (row0 + min(q, Lb - 1)) * a.H + head * 64;
 #pragma unroll
@@ -611,16 +638,11 @@ __global__ __launch_bounds__(1024 / QB, QB == 2 ? 2 : 4) void attn_full_kernel(A
 int launch_attn_bf16(const AttnArgs& a, hipStream_t st) {
     const int nt = a.Lp >> 6;
     const int lds = 2 * nt * 8192 + nt * 256;
-    static const char* v = getenv("OTTER_ATTN_QB");   // A/B switch for tuning runs
-    if (!(v && v[0] == '1')) {   // default: 8 waves x 64 queries (the 16-wave form spills at 128 VGPRs)
-        OTTER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<2>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(attn_full_kernel<2>, dim3(a.heads, a.B), dim3(512), lds, st, a);
-    } else {
-        OTTER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(attn_full_kernel<1>, dim3(a.heads, a.B), dim3(1024), lds, st, a);
-    }
+    // 8 waves x 64 queries.  (A 16-wave x 32-query form exists as attn_full_kernel<1>; it needs 128 registers per
+    // lane, spills, and is not launched: a kernel whose hidden asynchronous loads land in registers must not spill.)
+    OTTER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(attn_full_kernel<2>, dim3(a.heads, a.B), dim3(512), lds, st, a);
     OTTER_HIP_TRY(hipGetLastError());
     return OTTER_OK;
 }
