@@ -300,8 +300,8 @@ def small_batch_leg(index, q, k, n, d):
                     "hbm_frac_wall": byts / (wall_ms * 1e-3) / 1e9 / PEAK_HBM_GBS})
     return {"bound": "hbm", "peak_GBps": PEAK_HBM_GBS, "algorithmic_bytes_per_search": float(n) * d * 4,
             "kernel": "stream_kernel (<= 16 queries: lane = row, per-wave LDS-DMA rings with non-temporal loads, "
-                      "v_mfma_f32_4x4x1 fma chain, in-kernel threshold exchange) + one merge_kernel launch; 17 ... 32 "
-                      "queries: scan_kernel (32x32x2 tile) with a sample pass",
+                      "v_mfma_f32_4x4x1 fma chain, in-kernel threshold exchange) / stream32_kernel (17 ... 32 queries: "
+                      "v_mfma_f32_32x32x2 blocks, same structure) + one merge_kernel launch",
             "note": "scan_ms = HIP events around every kernel that reads corpus rows; wall_ms = host clock per "
                     "search() call incl. every side kernel and the launch gaps", "points": out}
 

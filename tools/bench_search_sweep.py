@@ -68,9 +68,18 @@ def main():
         kms = ms / max(n, 1)
         gbs = a.rows * a.dim * (2 if a.dtype == 'bf16' else 4) / (kms * 1e-3) / 1e9
         tf = 2.0 * a.rows * a.dim * nq / (kms * 1e-3) / 1e12
+        # which matrix pipe serves this point: fp32 index, <= 32 queries -> exact fp32 kernels (fp32 matrix peak);
+        # fp32 index, >= 33 queries -> coarse pass on bf16 planes (one product per term: the kernel's flops are
+        # bf16 flops against the bf16 peak; the fp32-equivalent ratio is printed beside it, it is not a roofline)
+        coarse16 = a.dtype == "bf16" or (nq >= 33 and a.rows >= 65536 and not os.environ.get("OTTER_NO_SPLIT"))
+        bytes_per = 2 if a.dtype == "bf16" else 4
         rec = {"nq": nq, "k": a.k, "rows": a.rows, "scan_ms": round(kms, 4), "wall_ms": round(wall, 4),
-               "GBps": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM, 4), "TFLOPs": round(tf, 2),
-               "mfma_frac": round(tf / (2500.0 if a.dtype == "bf16" else PEAK_F32), 4),
+               "GBps": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM, 4),
+               "hbm_frac_wall": round(a.rows * a.dim * bytes_per / (wall * 1e-3) / 1e9 / PEAK_HBM, 4),
+               "TFLOPs": round(tf, 2),
+               "mfma_pipe": "bf16" if coarse16 else "fp32",
+               "mfma_frac": round(tf / (2500.0 if coarse16 else PEAK_F32), 4),
+               "f32_equivalent_vs_f32_matrix_peak": round(tf / PEAK_F32, 4),
                "queries_per_s": round(nq / (wall * 1e-3), 1),
                "dtype": a.dtype, "fallback_queries": ix.last_fallback, "refined_queries": ix.last_refined}
         if ref is not None:
