@@ -91,8 +91,8 @@ int otter_index_search(otter_index* ix, const void* q, int64_t nq, int k,
 /* otter_index_search for callers that cannot allocate.  NO counterpart in the reference: it exists for callers
  * that cannot call hipMalloc -- code under HIP graph capture, tight serving loops (the reference's real call
  * pattern is one query per call, scripts/eval_ottqa_retrieval.py:126-129), harnesses that forbid allocation.
- * Same kernels and bit-identical results as otter_index_search; every byte of device scratch (padded queries,
- * per-strip candidate lists and counts, sample list and thresholds, merge levels) lives in ONE static 34 MiB
+ * Same kernels and bit-identical results as otter_index_search; every byte of device scratch (per-strip
+ * candidate lists and counts, block maxima and sync words of the threshold exchange) lives in ONE static 34 MiB
  * __device__ array per GPU that is part of the library's code object (each GPU the library runs on holds its
  * copy until the process ends).  The call issues no hipMalloc / hipFree and no allocating library routine, and
  * only enqueues work on `stream`.
