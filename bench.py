@@ -501,13 +501,13 @@ def main():
         del xb16
         torch.cuda.empty_cache()
         pts = []
-        for nq1 in (1, 16):
+        for nq1 in (1, 16, 32):
             s_ms, w_ms = timed_search(ix16, q[:nq1].contiguous(), k, 30, 5)
             pts.append({"nq": nq1, "scan_ms": s_ms, "wall_ms": w_ms, "GBps_wall": float(n) * d * 2 / (w_ms * 1e-3) / 1e9,
                         "hbm_frac_scan": float(n) * d * 2 / (s_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                         "hbm_frac_wall": float(n) * d * 2 / (w_ms * 1e-3) / 1e9 / PEAK_HBM_GBS})
         extra["small_batches_bf16_index"] = {"bound": "hbm", "algorithmic_bytes_per_search": float(n) * d * 2,
-                                             "kernel": "stream16_kernel (v_mfma_f32_16x16x32_bf16)", "points": pts}
+                                             "kernel": "stream16_kernel (v_mfma_f32_16x16x32_bf16; one block of 16 query columns up to 16 queries, two up to 32)", "points": pts}
         ix16.close()
         del ix16
         torch.cuda.empty_cache()

@@ -521,10 +521,11 @@ struct StreamArgs {
     int q_rows;          // rows that exist behind Q
     int seed;            // 1: threshold exchange on
     u64* bmax;           // [4 G][4 * strips] block maxima of every wave's first tile
-    u32* sync;           // [0] arrivals, [1] ready, [2..33] thresholds (keys); zero at launch, zeroed again by the merge
+    u32* sync;           // [0] arrivals, [1] ready (stream16_kernel: number of queries selected), [2..33] thresholds (keys),
+                         // [35] next query to select (stream16_kernel); zero at launch, zeroed again by the merge
 };
 
-constexpr int ST_BM = 256, ST_SYNC_WORDS = 34;
+constexpr int ST_BM = 256, ST_SYNC_WORDS = 36;    // [34] unused, [35] claim counter of the distributed selection (stream16_kernel)
 constexpr int st_qinstr(int G, int BK) { return (4 * G * BK * 4 + 1023) / 1024; }              // LDS-DMA instructions for the queries
 constexpr int st_slot(int G, int BK) { return 64 * BK * 4 + st_qinstr(G, BK) * 1024; }        // per wave and stage
 constexpr int st_ips(int G, int BK) { return BK / 4 + st_qinstr(G, BK); }                     // LDS-DMA instructions per wave and stage
@@ -1129,20 +1130,20 @@ __global__ __launch_bounds__(256) void stream32_kernel(StreamArgs a) {
 // (per-query threshold in LDS, candidate buffers, wave radix compaction).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// ------------------------------------------------------------------ stream kernel, bf16 storage (at most 16 queries)
+// ------------------------------------------------------------------ stream kernel, bf16 storage (at most 32 queries)
 // stream_kernel's structure on an OTTER_BF16 index: a wave streams its own 64 rows of every 256-row tile, one
 // 64-element K-slab (128 B per row; the planes are tile-blocked, so a wave's rows of a slab are 8 KiB of
 // consecutive bytes) per stage, v_mfma_f32_16x16x32_bf16 with scan16_kernel<0>'s operand roles and k order
 // (identical scores), the same threshold exchange, candidate path and merge.  X and Q are the bf16 planes;
 // a.ld is the row length in elements.
-template <int EPL, int ST_NSTAGE>
+template <int QG, int EPL, int ST_NSTAGE>
 __global__ __launch_bounds__(256) void stream16_kernel(StreamArgs a) {
-    constexpr int NQP = 16;                    // query columns of one 16x16x32 block
+    constexpr int NQP = 16 * QG;               // query columns: QG blocks of 16 (one 16x16x32 block each)
     constexpr int G = 4;                       // 16-row blocks of a wave's 64 rows
-    constexpr int ST_HOLD = 6;                 // tiles whose scores wait in registers for the thresholds (16 per tile)
+    constexpr int ST_HOLD = QG == 1 ? 6 : 3;   // tiles whose scores wait in registers for the thresholds (16 QG per tile)
     constexpr int ST_BK = 32;                  // (a stage = one 64-element K-slab = 128 bytes per row, as 32 floats are)
     constexpr int CAP = EPL * 64;
-    constexpr int QI = 2, ST_SLOT = 64 * 128 + QI * 1024, ST_IPS = 8 + QI;     // 16 query rows x 128 B
+    constexpr int QI = 2 * QG, ST_SLOT = 64 * 128 + QI * 1024, ST_IPS = 8 + QI;   // 16 QG query rows x 128 B
     constexpr int CH = ST_BK / 4;              // 16-byte chunks per row of a stage
     constexpr int RPI = 64 / CH;               // rows per LDS-DMA instruction
     static_assert(CAP - ST_BM >= 128, "candidate buffer too small");
@@ -1200,20 +1201,23 @@ __global__ __launch_bounds__(256) void stream16_kernel(StreamArgs a) {
     // ---- candidate path.  Lane l holds, per 16-row block g, the scores of rows 16 g + 4 (l >> 4) + i (i = 0..3)
     // of this wave's 64 for query l & 15
     const int rsub = wave * 64 + 4 * (lane >> 4);
-    auto append_tile = [&](const f32x4 (&sc)[G], int tile) {
-        const int q = lane & 15;
-        const u32 thr = sThr[q];
+    auto append_tile = [&](const f32x4 (&sc)[QG][G], int tile) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const long long row0 = (long long)tile * ST_BM + rsub + 16 * g;
+        for (int c = 0; c < QG; ++c) {
+            const int q = 16 * c + (lane & 15);
+            const u32 thr = sThr[q];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const u32 key = f2key(sc[g][i]);
-                if (q < a.nq && key >= thr && row0 + i < a.n) {
-                    const u32 pos = atomicAdd(&sCnt[q], 1u);
-                    if (pos < (u32)CAP)
-                        candBase[(u32)q * (u32)CAP + pos] = ((u64)key << 32) | (u64)(0xFFFFFFFFu - (u32)(row0 + i));
-                    if (pos + 1 > (u32)(CAP - ST_BM)) sFlag[0] = 1;
+            for (int g = 0; g < G; ++g) {
+                const long long row0 = (long long)tile * ST_BM + rsub + 16 * g;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u32 key = f2key(sc[c][g][i]);
+                    if (q < a.nq && key >= thr && row0 + i < a.n) {
+                        const u32 pos = atomicAdd(&sCnt[q], 1u);
+                        if (pos < (u32)CAP)
+                            candBase[(u32)q * (u32)CAP + pos] = ((u64)key << 32) | (u64)(0xFFFFFFFFu - (u32)(row0 + i));
+                        if (pos + 1 > (u32)(CAP - ST_BM)) sFlag[0] = 1;
+                    }
                 }
             }
         }
@@ -1237,13 +1241,15 @@ __global__ __launch_bounds__(256) void stream16_kernel(StreamArgs a) {
         wg_barrier();
     };
 
-    f32x4 acc[G];
-    f32x4 held[ST_HOLD][G];
+    f32x4 acc[QG][G];
+    f32x4 held[ST_HOLD][QG][G];
     int nheld = 0, held_tile0 = t0;
     bool have_thr = a.seed == 0;     // no exchange: thresholds are learned locally from the start
     bool got_global = a.seed == 0;   // the exchanged thresholds have been taken over (or there are none to wait for)
 #pragma unroll
-    for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < QG; ++c)
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[c][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
     for (int s2 = 0; s2 < ST_NSTAGE - 1; ++s2) issue_stage();
@@ -1268,12 +1274,16 @@ __global__ __launch_bounds__(256) void stream16_kernel(StreamArgs a) {
 #pragma unroll
             for (int ks2 = 0; ks2 < 2; ++ks2) {
                 const u32 co = ((4u * ks2 + fq) ^ rswz) << 4;
-                const float4 qf = *reinterpret_cast<const float4*>(sQ + rowoff + co);
+                float4 qf[QG];
+#pragma unroll
+                for (int c = 0; c < QG; ++c) qf[c] = *reinterpret_cast<const float4*>(sQ + c * 16 * 128 + rowoff + co);
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const float4 xf = *reinterpret_cast<const float4*>(sA + g * 16 * 128 + rowoff + co);
-                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf), __builtin_bit_cast(bf16x8, qf),
-                                                                     acc[g], 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < QG; ++c)
+                        acc[c][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf),
+                                                                            __builtin_bit_cast(bf16x8, qf[c]), acc[c][g], 0, 0, 0);
                 }
             }
         }
@@ -1286,13 +1296,16 @@ __global__ __launch_bounds__(256) void stream16_kernel(StreamArgs a) {
             for (int h = 0; h < ST_HOLD; ++h)
                 if (h == nheld)
 #pragma unroll
-                    for (int g = 0; g < G; ++g) held[h][g] = acc[g];
+                    for (int c = 0; c < QG; ++c)
+#pragma unroll
+                        for (int g = 0; g < G; ++g) held[h][c][g] = acc[c][g];
             ++nheld;
         }
         if (a.seed && tile == t0) {
             // publish the best row of this wave's first tile, per query (composites; 0 = no valid row)
-            {
-                const int q = lane & 15;
+#pragma unroll
+            for (int cg = 0; cg < QG; ++cg) {
+                const int q = 16 * cg + (lane & 15);
                 u64 c = 0ull;
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
@@ -1300,7 +1313,7 @@ __global__ __launch_bounds__(256) void stream16_kernel(StreamArgs a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const u64 v = (q < a.nq && row0 + i < a.n)
-                                          ? (((u64)f2key(acc[g][i]) << 32) | (u64)(0xFFFFFFFFu - (u32)(row0 + i))) : 0ull;
+                                          ? (((u64)f2key(acc[cg][g][i]) << 32) | (u64)(0xFFFFFFFFu - (u32)(row0 + i))) : 0ull;
                         c = v > c ? v : c;
                     }
                 }
@@ -1316,18 +1329,35 @@ __global__ __launch_bounds__(256) void stream16_kernel(StreamArgs a) {
             wait_vmcnt<0>();            // this wave's stores have left (once per launch: the ring drains with them)
         }
 #pragma unroll
-        for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < QG; ++c)
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[c][g] = f32x4{0.f, 0.f, 0.f, 0.f};
         wg_barrier();                   // tile boundary: every wave has appended / published
-        if (a.seed && tile == t0) {
+        // Threshold exchange, selection shared out: once every workgroup has published its block maxima
+        // (arrivals == strips), any workgroup that reaches a tile boundary claims four queries (one per wave) and
+        // selects their k-th best block maximum; sync[1] counts the queries done.  Nobody waits for anybody: a
+        // workgroup only ever looks at the counters when it is at a tile boundary anyway.  (One workgroup selecting
+        // all 32 queries takes about 50 us, more than the three tiles this kernel can hold at bf16 speed.)
+        if (!got_global) {
             if (tid == 0) {
-                const u32 old = __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sFlag[2] = (old == (u32)a.strips - 1u) ? 1u : 0u;
+                u32 arr = 0u;
+                if (tile == t0) arr = __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+                else arr = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u32 done = __hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u32 claim = 0xFFFFFFFFu;
+                if (arr == (u32)a.strips && done < (u32)a.nq) {
+                    const u32 c = __hip_atomic_fetch_add(a.sync + 35, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (c < (u32)a.nq) claim = c;
+                }
+                sFlag[2] = claim;
+                sFlag[1] = done >= (u32)a.nq ? 1u : 0u;
             }
             wg_barrier();
-            if (sFlag[2]) {
-                // last arrival: every block maximum is published.  Wave w selects for queries w, w + 4, ...
+            const u32 claim = sFlag[2];
+            if (claim != 0xFFFFFFFFu) {
                 const int M = 4 * a.strips;          // <= 1024 (host)
-                for (int q = wave; q < a.nq; q += 4) {
+                const int q = (int)claim + wave;
+                if (q < a.nq) {
                     u64 x[16];
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
@@ -1344,18 +1374,12 @@ __global__ __launch_bounds__(256) void stream16_kernel(StreamArgs a) {
                 }
                 wait_vmcnt<0>();
                 wg_barrier();
-                if (tid == 0) __hip_atomic_store(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0)
+                    __hip_atomic_fetch_add(a.sync + 1, (u32)min(4, a.nq - (int)claim), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-        }
-        if (!got_global) {
-            // thresholds there yet?  (one sc1 poll per tile boundary; nobody waits)
-            if (wave == 0) {
-                const u32 r = __hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (r && lane < a.nq) {
-                    const u32 t = __hip_atomic_load(a.sync + 2 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    sThr[lane] = max(sThr[lane], t);
-                }
-                if (lane == 0) sFlag[1] = r;
+            if (sFlag[1] != 0u && tid < a.nq) {
+                const u32 t = __hip_atomic_load(a.sync + 2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sThr[tid] = max(sThr[tid], t);
             }
             wg_barrier();
             const bool ready = sFlag[1] != 0u;
@@ -2452,10 +2476,10 @@ void launch_stream32(const StreamArgs& a, int grid, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
 }
 
-template <int EPL, int NSTAGE>
+template <int QG, int EPL, int NSTAGE>
 void launch_stream16(const StreamArgs& a, int grid, hipStream_t st) {
-    auto kern = stream16_kernel<EPL, NSTAGE>;
-    const int lds = 4 * NSTAGE * (64 * 128 + 2 * 1024) + 67 * (int)sizeof(u32);
+    auto kern = stream16_kernel<QG, EPL, NSTAGE>;
+    const int lds = 4 * NSTAGE * (64 * 128 + 2 * QG * 1024) + 67 * (int)sizeof(u32);
     static bool attr_set[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -2689,7 +2713,7 @@ int search_chunk_stream(otter_index* ix, const float* qd, long long nq, int k, f
                         Scratch* sc, const void* q16_plane = nullptr) {
     constexpr int EPL = 8, CAP = EPL * 64;
     const bool b16 = ix->dtype == OTTER_BF16;       // stream16_kernel: q16_plane = the queries' bf16 plane (16 columns)
-    const int G = b16 ? 4 : nq <= 4 ? 1 : nq <= 8 ? 2 : nq <= 16 ? 4 : 8;
+    const int G = nq <= 16 ? (b16 ? 4 : nq <= 4 ? 1 : nq <= 8 ? 2 : 4) : 8;     // query columns / 4
     const int nqp = 4 * G;
     const int total_tiles = (int)((ix->n + ST_BM - 1) / ST_BM);
     int strips = std::min(std::min(ix->ncu, NA_MAX_STRIPS), total_tiles);
@@ -2743,7 +2767,8 @@ int search_chunk_stream(otter_index* ix, const float* qd, long long nq, int k, f
         OTTER_HIP_TRY(hipEventRecord(ev.first, st));
     }
     // (ring depth by LDS: 4 waves x slots x (8 KiB + queries))
-    if (b16) launch_stream16<EPL, 3>(sa, strips, st);
+    if (b16 && G <= 4) launch_stream16<1, EPL, 3>(sa, strips, st);
+    else if (b16) launch_stream16<2, EPL, 3>(sa, strips, st);
     else if (G == 1) launch_stream<1, EPL, 32, 4>(sa, strips, st);
     else if (G == 2) launch_stream<2, EPL, 32, 4>(sa, strips, st);
     else if (G == 4) launch_stream<4, EPL, 32, 3>(sa, strips, st);
@@ -3055,7 +3080,7 @@ int search_chunk_bf16(otter_index* ix, const float* qd, long long nq, int k, flo
         OTTER_HIP_TRY(hipGetLastError());
     }
     static const char* no_stream = getenv("OTTER_NO_STREAM");
-    if (nq <= 16 && k <= 128 && !no_stream) {
+    if (nq <= 32 && k <= 128 && !no_stream) {
         Scratch own;
         return search_chunk_stream(ix, qd, nq, k, D, I, st, &own, ix->qs.p);
     }

@@ -17,9 +17,16 @@ for name, s, e, g, w in rows:
 for name, (c, ns) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:16]:
     short = name.replace("(anonymous namespace)::", "").replace("void ", "")[:70]
     print("%-70s calls %5d  total %9.1f us  avg %8.1f us" % (short, c, ns / 1e3, ns / 1e3 / c))
-print("== last %d dispatches" % n_last)
+window = rows[-n_last:]
+if len(sys.argv) > 3:
+    # [n_last] [substring]: the window ends n_last // 3 dispatches after the last dispatch whose name contains it
+    idx = [i for i, r in enumerate(rows) if sys.argv[3] in r[0]]
+    if idx:
+        hi = min(len(rows), idx[-1] + 1 + n_last // 3)
+        window = rows[max(0, hi - n_last):hi]
+print("== %d dispatches" % len(window))
 prev = None
-for name, s, e, g, w in rows[-n_last:]:
+for name, s, e, g, w in window:
     short = name.replace("(anonymous namespace)::", "").replace("void ", "")[:44]
     print("%-44s dur %8.1f us  gap %6.1f us  wgs %5d x %4d" % (short, (e - s) / 1e3, ((s - prev) / 1e3 if prev else 0.0), g // max(w, 1), w))
     prev = e
