@@ -2553,6 +2553,7 @@ struct otter_index {
     otter::DevBuf qs, qnorm2, cD, cI, rs, rscnt, flags, fb_q, fb_D, fb_I;
     otter::DevBuf qpad, cand, cnt, lvl[2], lvlcnt[2], smp, smpcnt, thr0, io_q, io_D, io_I, bmax, sync;
     bool sync_dirty = true;         // the stream kernel's counters are not known to be zero
+    u32* h_flag = nullptr;          // pinned word for the one read-back of a coarse pass
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
 };
@@ -3210,7 +3211,9 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
     hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)std::min<long long>((nq_pad + 3) / 4, 16384)), dim3(256), 0, st,
                        qd, (long long)ix->d, (unsigned short*)ix->qs.p, nq, nq_pad, ix->d, ix->ld, (float*)ix->qnorm2.p,
                        0ll, (float*)ix->qres2.p);
-    {
+    // the re-scoring reads the fp32 query rows: in place when the caller's rows already have the padded length
+    const bool q_in_place = ix->ld == ix->d && ((uintptr_t)qd & 15) == 0;
+    if (!q_in_place) {
         const long long total = nq_pad * ix->ld;
         hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0,
                            st, qd, (float*)ix->qpad.p, nq, nq_pad, ix->d, ix->ld);
@@ -3230,7 +3233,7 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
     if (rc) return rc;
     RescoreArgs ra;
     ra.X = ix->x;
-    ra.Q = (const float*)ix->qpad.p;
+    ra.Q = q_in_place ? qd : (const float*)ix->qpad.p;
     ra.Ic = (const long long*)ix->cI.p;
     ra.out = (u64*)ix->rs.p;
     ra.out_cnt = (u32*)ix->rscnt.p;
@@ -3254,10 +3257,11 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
     OTTER_HIP_TRY(hipGetLastError());
     // the one host round trip of this pass (4 bytes): how many queries are left without a proof.  The
     // stream is synchronised here -- once per pass of a large-batch search (see include/otter_hip.h).
-    u32 nf_host = 0;
-    OTTER_HIP_TRY(hipMemcpyAsync(&nf_host, flags + nq, sizeof(u32), hipMemcpyDeviceToHost, st));
+    // (into pinned memory: a copy to a pageable word goes through a staging buffer and a second wait)
+    if (!ix->h_flag) OTTER_HIP_TRY(hipHostMalloc((void**)&ix->h_flag, 64, hipHostMallocDefault));
+    OTTER_HIP_TRY(hipMemcpyAsync(ix->h_flag, flags + nq, sizeof(u32), hipMemcpyDeviceToHost, st));
     OTTER_HIP_TRY(hipStreamSynchronize(st));
-    const long long nf = nf_host;
+    const long long nf = *ix->h_flag;
     if (mode >= 2 && first) ix->last_refined += nf;
     if (mode == 3 && nf * 4 > nq) ix->one_prod_off = true;
     if (mode == 2 && nf * 4 > nq) ix->two_prod_off = true;
@@ -3676,6 +3680,7 @@ void otter_index_destroy(otter_index* ix) {
     ix->io_q.release();
     ix->io_D.release();
     ix->io_I.release();
+    if (ix->h_flag) (void)hipHostFree(ix->h_flag);
     delete ix;
 }
 
