@@ -128,6 +128,11 @@ def predict(model, eval_dataloader, to_cpu=True, device=None):
                                    [_PipeSlot(True), _PipeSlot(True)])
         copy_stream, down_stream, slots = _PIPE_CACHE[device]
         cur = torch.cuda.current_stream(device)
+        for s in slots:                  # a call that raised half way must not leave its batches to the next one
+            if s.busy:
+                if s.ran:
+                    s.ev_fwd.synchronize()
+                s.out_dev, s.busy = None, False
     else:
         copy_stream = down_stream = cur = None
         slots = [_PipeSlot(False), _PipeSlot(False)]
