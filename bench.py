@@ -157,7 +157,7 @@ def encode_leg(rank, world, local_rank, dist, steps, warmup, batch, cpu_ref, reh
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    emb = predict(model, (hbs[i % nb_distinct] for i in range(steps)))
+    emb = predict(model, [hbs[i % nb_distinct] for i in range(steps)])      # (a list: predict() sizes its result once)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

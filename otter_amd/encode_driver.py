@@ -65,7 +65,9 @@ class _PipeSlot:
                 continue
             n = src.numel()
             pin = self._flat(self.pin, name, n, torch.int64, True)[:n].view(src.shape)
-            pin.copy_(src)
+            # (a plain memcpy: torch's copy_ fans 512 KB out over its thread pool, whose wake-up after an idle
+            # phase was measured at up to 32 ms -- with nothing queued on the GPU behind it)
+            np.copyto(pin.numpy(), src.numpy())
             devt = self._flat(self.dev, name, n, torch.int64, False, device)[:n].view(src.shape)
             with torch.cuda.stream(copy_stream):
                 devt.copy_(pin, non_blocking=True)
@@ -92,12 +94,18 @@ class _PipeSlot:
             self.out_pin[:n].view(self.rows, self.dim).copy_(embed, non_blocking=True)
             self.ev_d2h.record(down_stream)
 
-    def collect(self, to_cpu):
-        """The finished batch's embeddings (host copy when to_cpu); frees the slot."""
+    def collect(self, to_cpu, sink=None):
+        """The finished batch's embeddings (host copy when to_cpu); frees the slot.  `sink(rows, dim)` may hand out
+        the rows of a preallocated result to copy into (no per-batch allocation, no concatenation at the end)."""
         emb = self.out_dev
         if to_cpu and self.use_cuda and emb.is_cuda:
             self.ev_d2h.synchronize()
-            emb = self.out_pin[:self.rows * self.dim].view(self.rows, self.dim).clone()
+            src = self.out_pin[:self.rows * self.dim].view(self.rows, self.dim)
+            dst = sink(self.rows, self.dim) if sink is not None else None
+            if dst is None:
+                dst = torch.empty((self.rows, self.dim), dtype=torch.float32)
+            np.copyto(dst.numpy(), src.numpy())      # (memcpy, see upload)
+            emb = dst
         elif to_cpu:
             emb = emb.cpu()
         self.out_dev = None
@@ -137,6 +145,23 @@ def predict(model, eval_dataloader, to_cpu=True, device=None):
         copy_stream = down_stream = cur = None
         slots = [_PipeSlot(False), _PipeSlot(False)]
     embed_array = []
+    # a loader that knows its length lets the host result be allocated once (rows of the first batch x batches is an
+    # upper bound: only the last batch of a loader is short); every batch is then copied into place while the GPU
+    # works, instead of one concatenation of the whole result after the last batch
+    nbatches = len(eval_dataloader) if hasattr(eval_dataloader, "__len__") else None
+    whole = {"buf": None, "rows": 0}
+
+    def sink(rows, dim):
+        if nbatches is None or not (to_cpu and use_cuda):
+            return None
+        if whole["buf"] is None:
+            whole["buf"] = torch.empty((rows * nbatches, dim), dtype=torch.float32)
+        if whole["buf"].shape[1] != dim or whole["rows"] + rows > whole["buf"].shape[0]:
+            return None                  # (a loader whose batches grow: fall back to the list)
+        lo = whole["rows"]
+        whole["rows"] = lo + rows
+        return whole["buf"][lo:lo + rows]
+
     it = iter(eval_dataloader)
 
     def stage(i):
@@ -146,7 +171,7 @@ def predict(model, eval_dataloader, to_cpu=True, device=None):
             return None
         s = slots[i % 2]
         if s.busy:                       # its previous batch (i - 2) has not been collected yet
-            embed_array.append(s.collect(to_cpu))
+            embed_array.append(s.collect(to_cpu, sink))
         return s.upload(batch, device, copy_stream)
 
     i = 0
@@ -161,13 +186,16 @@ def predict(model, eval_dataloader, to_cpu=True, device=None):
         pending.append(s)
         # stage batch i + 1 while batch i computes; its slot holds batch i - 1, collected first
         if len(pending) == 2:
-            embed_array.append(pending.pop(0).collect(to_cpu))
+            embed_array.append(pending.pop(0).collect(to_cpu, sink))
         i += 1
         nxt = stage(i)
     for s in pending:
-        embed_array.append(s.collect(to_cpu))
+        embed_array.append(s.collect(to_cpu, sink))
     if not embed_array:
         raise ValueError("predict: the dataloader produced no batches")
+    buf = whole["buf"]
+    if buf is not None and all(e.untyped_storage().data_ptr() == buf.untyped_storage().data_ptr() for e in embed_array):
+        return buf[:whole["rows"]]       # every batch went into the preallocated result, in order
     return torch.cat(embed_array, dim=0)
 
 
