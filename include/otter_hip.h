@@ -148,7 +148,9 @@ int otter_index_timing(otter_index* ix, double* scan_ms, int64_t* scan_launches)
  * (they are built by the first search of 33 and more queries: once the corpus' bytes again for the hi/lo planes,
  * half of them again for the one-product plane), 1 = built and in use, 2 = HBM had no room for them, so the exact
  * fp32 kernel serves every batch size (about 1/6 of the rate at 2,214 queries; a note goes to stderr once),
- * 3 = not an OTTER_F32 index. */
+ * 3 = not an OTTER_F32 index, 4 = switched off for this corpus until reset(): even the three-product pass left more
+ * than a quarter of a batch unproven (scores closer together than bf16 products resolve, e.g. near-duplicate rows),
+ * so the exact kernel serves every batch instead of paying for coarse passes that prove nothing. */
 int otter_index_coarse_state(const otter_index* ix);
 
 /* Diagnostic (no counterpart in the reference).  Large query batches on an OTTER_F32 index run a

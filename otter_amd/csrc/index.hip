@@ -2549,6 +2549,8 @@ struct otter_index {
     otter::DevBuf xh, xres2, xrmax, qh16, fb3_q, fb3_D, fb3_I;
     long long xh_rows = 0, xh_cap = 0;
     bool xh_failed = false, one_prod_off = false;
+    bool coarse_off = false;        // even the three-product pass left > 1/4 of a batch unproven (scores within rounding of each
+                                    // other, e.g. near-duplicate rows): this corpus is searched by the exact kernel from then on
     long long last_stage0_unproven = 0;
     otter::DevBuf qs, qnorm2, cD, cI, rs, rscnt, flags, fb_q, fb_D, fb_I;
     otter::DevBuf qpad, cand, cnt, lvl[2], lvlcnt[2], smp, smpcnt, thr0, io_q, io_D, io_I, bmax, sync;
@@ -2798,7 +2800,7 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
         static const int split_min = split_min_env ? atoi(split_min_env) : 33;   // above the 32-query tile of the exact kernel, the
                                                                                  // last one that is HBM-bound (measured: 33..64 queries 1.0 -> 0.7 ms)
         static const char* mode_env = getenv("OTTER_SPLIT_MODE");          // "1": three-product coarse pass first
-        if (!no_split_env && !ix->no_split && nq >= split_min && ix->n >= 65536 && split_kc(k, 1, ix->d) <= S16_MAX_K) {
+        if (!no_split_env && !ix->no_split && !ix->coarse_off && nq >= split_min && ix->n >= 65536 && split_kc(k, 1, ix->d) <= S16_MAX_K) {
             const int rs = ensure_split_planes(ix, st);
             if (rs < 0) return rs;
             if (rs == 0) {
@@ -3265,6 +3267,13 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
     if (mode >= 2 && first) ix->last_refined += nf;
     if (mode == 3 && nf * 4 > nq) ix->one_prod_off = true;
     if (mode == 2 && nf * 4 > nq) ix->two_prod_off = true;
+    if (mode == 1 && nf * 4 > nq) {
+        if (!ix->coarse_off)
+            fprintf(stderr, "[libotter_hip] note: the coarse pass could not prove %lld of %lld queries on this index (scores closer "
+                            "than bf16 products resolve); batches are served by the exact fp32 kernel until reset() "
+                            "(otter_index_coarse_state() reports 4)\n", nf, nq);
+        ix->coarse_off = true;
+    }
     if (mode == 1) ix->last_fallback += nf;
     if (nf == 0) return OTTER_OK;
     // unproven queries: gather them, search them again one level down, scatter the rows back
@@ -3605,6 +3614,7 @@ int otter_index_reset(otter_index* ix) {
     ix->xs_rows = 0;
     ix->two_prod_off = false;
     ix->one_prod_off = false;
+    ix->coarse_off = false;
     ix->xh_rows = 0;
     if (ix->xrmax.p) {
         DeviceGuard g2(ix->device);
@@ -3651,6 +3661,7 @@ int otter_index_coarse_state(const otter_index* ix) {
     if (!ix) return set_err(OTTER_EINVAL, "coarse_state: index is NULL");
     if (ix->dtype != OTTER_F32) return 3;
     if (ix->xs_failed) return 2;
+    if (ix->coarse_off) return 4;
     return ix->xs_rows >= ix->n && ix->n > 0 && ix->xs.p ? 1 : 0;
 }
 

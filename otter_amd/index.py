@@ -226,7 +226,8 @@ class IndexFlatIP:
     @property
     def coarse_state(self):
         """0: bf16 planes of the coarse pass not built yet, 1: in use, 2: no room in HBM (the exact kernel serves
-        every batch size), 3: not an fp32 index."""
+        every batch size), 3: not an fp32 index, 4: switched off for this corpus until reset() (its proofs failed for
+        most queries: scores closer together than bf16 products resolve)."""
         return int(self._lib.otter_index_coarse_state(self._h))
 
     @property

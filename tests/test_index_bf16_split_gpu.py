@@ -164,3 +164,31 @@ def test_bf16_index_incremental_device_add_and_limits():
     D, I = ix.search(q, 5)
     assert (I == -1).all()
     ix.close()
+
+
+def test_coarse_pass_switches_itself_off_on_a_corpus_it_cannot_prove():
+    """Near-duplicate rows: every coarse pass leaves most queries unproven, the exact kernel re-does them.  After one
+    such batch the index stops paying for coarse passes (coarse_state 4) until reset(); results stay the oracle's."""
+    from otter_amd.index import IndexFlatIP
+    rng = np.random.RandomState(4)
+    n, d, nq, k = 70000, 256, 120, 50
+    proto = rng.randn(30, d).astype(np.float32)
+    xb = (proto[rng.randint(0, 30, size=n)] * (1.0 + 1e-6 * rng.randn(n, 1).astype(np.float32))).astype(np.float32)
+    q = rng.randn(nq, d).astype(np.float32)
+    Dr, Ir = flat_ip.search_c(xb, q, k, mode=flat_ip.MODE_GPU_ORDER)
+    ix = IndexFlatIP(d)
+    ix.add(xb)
+    D, I = ix.search(q, k)
+    assert ix.last_fallback > nq // 4 and ix.coarse_state == 4
+    np.testing.assert_array_equal(I, Ir)
+    np.testing.assert_array_equal(D.view(np.uint32), Dr.view(np.uint32))
+    D2, I2 = ix.search(q, k)                          # served by the exact kernel alone
+    assert ix.last_fallback == 0
+    np.testing.assert_array_equal(I2, Ir)
+    np.testing.assert_array_equal(D2.view(np.uint32), Dr.view(np.uint32))
+    ix.reset()
+    g = np.random.RandomState(5).randn(n, d).astype(np.float32)
+    ix.add(g)
+    ix.search(q, k)
+    assert ix.coarse_state == 1 and ix.last_fallback == 0
+    ix.close()
