@@ -837,7 +837,7 @@ __global__ __launch_bounds__(256) void stream_kernel(StreamArgs a) {
 //           interleaved per 32 values of k as [hi(32) | lo(32)] (128 B), and the score is
 //           x_hi q_hi + x_hi q_lo + x_lo q_hi (the dropped terms are <= 3 * 2^-16 |x_k q_k| each).
 //           The caller keeps k + margin candidates by this coarse score, re-scores them exactly
-//           (rescore_kernel: the fp32 fma chain of scan_kernel) and proves the margin sufficient
+//           (rescore_lds_kernel: the fp32 fma chain of scan_kernel) and proves the margin sufficient
 //           (margin_check_kernel) or falls back to scan_kernel for that query.
 // Structure: the encoder GEMM's persistent ping-pong main loop (gemm_bf16.hip: 8 waves = 2 groups
 // one barrier apart, 256 x 256 tile, K-step of 128 B rows as four 16 KiB half-tiles, LDS-DMA six
@@ -1120,7 +1120,7 @@ __global__ __launch_bounds__(256) void stream32_kernel(StreamArgs a) {
 //           interleaved per 32 values of k as [hi(32) | lo(32)] (128 B), and the score is
 //           x_hi q_hi + x_hi q_lo + x_lo q_hi (the dropped terms are <= 3 * 2^-16 |x_k q_k| each).
 //           The caller keeps k + margin candidates by this coarse score, re-scores them exactly
-//           (rescore_kernel: the fp32 fma chain of scan_kernel) and proves the margin sufficient
+//           (rescore_lds_kernel: the fp32 fma chain of scan_kernel) and proves the margin sufficient
 //           (margin_check_kernel) or falls back to scan_kernel for that query.
 // Structure: the encoder GEMM's persistent ping-pong main loop (gemm_bf16.hip: 8 waves = 2 groups
 // one barrier apart, 256 x 256 tile, K-step of 128 B rows as four 16 KiB half-tiles, LDS-DMA six
@@ -1850,50 +1850,79 @@ struct RescoreArgs {
     int ld, kc, k, nq_pad;
 };
 
-__global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// The candidate rows are gathered through LDS.  Loading the 32x32x2 fragments straight from global memory touches 32
+// rows x 32 bytes per instruction (a lane group owns a row's k-pair); here a load instruction takes whole 128-byte
+// lines -- 8 lanes per row, 8 rows per instruction -- into registers, the wave writes them to its own LDS buffer in
+// the swizzled row image the stream kernels use, and reads the fragments from there (round 1's direct form: 0.37 ms
+// for 2214 x 211 rows of 768 floats, this one 0.30; 1.79 -> 1.60 ms at d = 2304, 3.03 -> 2.73 ms at k = 1000).
+// No barrier: a wave only ever touches its own two 4 KiB buffers.
+template <bool QLDS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 3))) void rescore_lds_kernel(RescoreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char rsm[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = (int)(blockDim.x >> 6);
     const int q = blockIdx.x;
     const int h = lane >> 5, l31 = lane & 31;
     const float* qrow = a.Q + (size_t)q * a.ld;
-    for (int c0 = wave * 32; c0 < a.kc; c0 += 128) {
+    char* wbuf = rsm + wave * 8192;                       // [2][32 rows][128 B]
+    float* sQ = reinterpret_cast<float*>(rsm + nw * 8192);
+    if (QLDS) {
+        for (int i = threadIdx.x; i < a.ld / 4; i += (int)blockDim.x)
+            reinterpret_cast<float4*>(sQ)[i] = reinterpret_cast<const float4*>(qrow)[i];
+        __syncthreads();
+    }
+    const int S = a.ld / 32;                              // steps of 32 floats (ld is a multiple of 64: S is even)
+    const int lr = lane >> 3, lc = lane & 7;              // this lane's row within an instruction's 8, its 16-byte chunk
+    for (int c0 = wave * 32; c0 < a.kc; c0 += nw * 32) {
         const int ci = c0 + l31;
         const long long id = ci < a.kc ? a.Ic[(size_t)q * a.kc + ci] : -1ll;
         const long long row = id >= 0 ? id - a.id_base : 0;
-        const float* xrow = a.X + (size_t)row * a.ld;
+        // rows 8 i + lr (i = 0..3) are the ones this lane fetches: their ids sit in lanes 8 i + lr
+        const f32x4* src[4];
+        u32 wofs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + lr;
+            const long long rr = __shfl(row, r);
+            src[i] = reinterpret_cast<const f32x4*>(a.X + (size_t)rr * a.ld) + lc;
+            wofs[i] = (u32)r * 128u + (u32)((lc ^ ((r >> 1) & 7)) << 4);
+        }
+        const u32 rofs = (u32)l31 * 128u;
+        const u32 rswz = (u32)((l31 >> 1) & 7);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        // a gather of 32 scattered rows: the loads of the next four k-groups are in flight while the current
-        // four are multiplied (same MFMA sequence as the plain loop: the sums are unchanged)
-        constexpr int U = 4;
-        const int nj = a.ld / 8, njU = nj / U * U;
-        float4 af[2][U], bf[2][U];
-        auto fetch = [&](int buf, int j0) {
+        f32x4 preA[4], preB[4];      // (native vectors: arrays of HIP's float4 class stay in private memory)
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                af[buf][u] = *reinterpret_cast<const float4*>(xrow + 8 * (j0 + u) + 4 * h);
-                bf[buf][u] = *reinterpret_cast<const float4*>(qrow + 8 * (j0 + u) + 4 * h);
-            }
-        };
-        auto mul = [&](const float4& x, const float4& q) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, q.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, q.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, q.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, q.w, acc, 0, 0, 0);
-        };
-        if (njU) fetch(0, 0);
-        for (int j0 = 0; j0 < njU; j0 += 2 * U) {
-            if (j0 + U < njU) fetch(1, j0 + U);
-#pragma unroll
-            for (int u = 0; u < U; ++u) mul(af[0][u], bf[0][u]);
-            if (j0 + U < njU) {
-                if (j0 + 2 * U < njU) fetch(0, j0 + 2 * U);
-#pragma unroll
-                for (int u = 0; u < U; ++u) mul(af[1][u], bf[1][u]);
-            }
+        for (int i = 0; i < 4; ++i) {
+            preA[i] = src[i][0];
+            preB[i] = src[i][8];                          // (step s: + 8 s float4 = 128 bytes per step)
         }
-        for (int j = njU; j < nj; ++j)
-            mul(*reinterpret_cast<const float4*>(xrow + 8 * j + 4 * h), *reinterpret_cast<const float4*>(qrow + 8 * j + 4 * h));
+        auto step = [&](int s2, f32x4 (&pre)[4], char* buf) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(buf + wofs[i]) = pre[i];
+            if (s2 + 2 < S) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pre[i] = src[i][8 * (s2 + 2)];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 x = *reinterpret_cast<const float4*>(buf + rofs + ((((u32)(2 * j + h)) ^ rswz) << 4));
+                const float4 qf = QLDS ? *reinterpret_cast<const float4*>(sQ + 32 * s2 + 8 * j + 4 * h)
+                                       : *reinterpret_cast<const float4*>(qrow + 32 * s2 + 8 * j + 4 * h);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, qf.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, qf.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, qf.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, qf.w, acc, 0, 0, 0);
+            }
+        };
+        for (int s2 = 0; s2 < S; s2 += 2) {
+            step(s2, preA, wbuf);
+            step(s2 + 1, preB, wbuf + 4096);
+        }
         // lane (column l31, half h) holds rows (r & 3) + 8 (r >> 2) + 4 h; all columns are equal:
         // column 0's two lanes publish the 32 scores
 #pragma unroll
@@ -1918,6 +1947,21 @@ __global__ __launch_bounds__(256) void rescore_kernel(RescoreArgs a) {
         const int S2 = (a.kc + a.k - 1) / a.k;
         for (int s = lane; s < S2; s += 64) a.out_cnt[(size_t)s * a.nq_pad + q] = (u32)max(0, min(a.k, valid - s * a.k));
     }
+}
+
+// up to 8 waves per query, one 32-candidate group each; the query row staged in LDS when it fits beside the buffers
+void launch_rescore(const RescoreArgs& ra, unsigned grid, hipStream_t st) {
+    // waves = 32-candidate groups spread evenly over as few rounds as the waves allow (10 groups: 2 rounds of 5);
+    // at most 8 waves, and no more than leave room for the query row beside their buffers in 64 KiB of LDS
+    const size_t qbytes = (size_t)ra.ld * 4;
+    const bool qlds = qbytes <= 32768;
+    const int max_w = qlds ? std::min(8, (int)((65536 - qbytes) / 8192)) : 8;
+    const int groups = std::max(1, (ra.kc + 31) / 32), rounds = (groups + max_w - 1) / max_w;
+    const int nw = (groups + rounds - 1) / rounds;
+    if (qlds)
+        hipLaunchKernelGGL(rescore_lds_kernel<true>, dim3(grid), dim3(64 * nw), (size_t)nw * 8192 + qbytes, st, ra);
+    else
+        hipLaunchKernelGGL(rescore_lds_kernel<false>, dim3(grid), dim3(64 * nw), (size_t)nw * 8192, st, ra);
 }
 
 // A query's exact top k is proven complete when its k-th exact score exceeds every score a row
@@ -3244,7 +3288,7 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
     ra.kc = kc;
     ra.k = k;
     ra.nq_pad = (int)nq_pad;
-    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)nq), dim3(256), 0, st, ra);
+    launch_rescore(ra, (unsigned)nq, st);
     OTTER_HIP_TRY(hipGetLastError());
     if ((rc = run_merge(ix, (const u64*)ix->rs.p, (const u32*)ix->rscnt.p, k, S2, nq, nq_pad, k, true, D, I, nullptr,
                         nullptr, nullptr, nullptr, nullptr, st)))
@@ -3476,7 +3520,7 @@ int otter_index_search_noalloc(otter_index* ix, const float* q, int64_t nq, int 
 // Search restricted to per-query id subsets: the reference builds a throw-away
 // faiss.IndexFlatIP over the TF-IDF-filtered blocks of every question and searches it with that one
 // question (retrieval/eval_ottqa_retrieval_tfidffilter.py:530-546).  Here the corpus stays resident: the
-// listed rows are gathered and scored with the exact kernel's fp32 chain (rescore_kernel), then selected
+// listed rows are gathered and scored with the exact kernel's fp32 chain (rescore_lds_kernel), then selected
 // by the merge kernel; scores are bit-identical to those search() returns for the same rows.
 int otter_index_search_subset(otter_index* ix, const void* q, int64_t nq, int k, const int64_t* ids, int m, float* D,
                               int64_t* I, int io_is_device, void* stream) {
@@ -3547,7 +3591,7 @@ int otter_index_search_subset(otter_index* ix, const void* q, int64_t nq, int k,
         ra.kc = m;
         ra.k = k;
         ra.nq_pad = (int)c_pad;
-        hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)c), dim3(256), 0, st, ra);
+        launch_rescore(ra, (unsigned)c, st);
         OTTER_HIP_TRY(hipGetLastError());
         if ((rc = run_merge(ix, (const u64*)ix->rs.p, (const u32*)ix->rscnt.p, k, S2, c, c_pad, k, true, Dd, Id, nullptr,
                             nullptr, nullptr, nullptr, nullptr, st)))
