@@ -252,6 +252,8 @@ def scan16_dispatches(n, nq, k, d, nprod):
     wgs = max(1, ncu // qtiles)
     cover = total // (4 if qtiles >= 8 else 8)
     l0 = max(1, -(-4 * kk // (wgs * 256))) * wgs
+    if l0 == wgs:
+        l0 = min(wgs, max(-(-4 * kk // 256), 16, min(32, wgs // 2)))
     if l0 > total // 8:
         return 1
     more, c = 0, l0

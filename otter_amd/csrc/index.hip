@@ -3025,6 +3025,14 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
     if (!no_sample) {
         int l0 = std::max(1, (int)((4ll * kk + (long long)wgs * S16_BM - 1) / ((long long)wgs * S16_BM))) * wgs;
         if (per_env) l0 = std::max(1, atoi(per_env)) * wgs;
+        static const char* l0s_env = getenv("OTTER_SAMPLE_L0_STRIPS");   // tuning runs only: one-tile strips of level 0
+        // One tile per workgroup is far more than the 4 kk rows level 0 needs when few query tiles leave many workgroups
+        // per tile: 16 ... 32 one-tile strips (half the workgroups in between) give a looser first threshold -- level 1
+        // appends more -- but a dump the first merge takes whole (<= 32 strips x 256 rows fit its pool) and selects from
+        // quickly.  Measured, 1M x 768: 64 queries 0.49 -> 0.43 ms, 256: 0.66 -> 0.53, 1024: 1.75 -> 1.63, 2214: -1 %.
+        const int l0_min = (int)((4ll * kk + S16_BM - 1) / S16_BM);
+        if (!per_env && l0 == wgs) l0 = std::min(wgs, std::max(std::max(l0_min, 16), std::min(32, wgs / 2)));
+        if (l0s_env) l0 = std::min(wgs, std::max(l0_min, atoi(l0s_env)));
         if (max_levels == 1) l0 = std::max(l0, (std::max(cover, (int)((64ll * kk + S16_BM - 1) / S16_BM)) + wgs - 1) / wgs * wgs);
         if (l0 <= total_tiles / 8) {
             lv_tiles[nlv++] = l0;
