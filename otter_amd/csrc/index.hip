@@ -2757,9 +2757,11 @@ bool g_scratch_sync_dirty[64] = {};
 
 // at most 32 queries, k <= 128: the stream kernel + one merge (no sample pass, no pad kernel for aligned rows)
 int search_chunk_stream(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st,
-                        Scratch* sc, const void* q16_plane = nullptr) {
-    constexpr int EPL = 8, CAP = EPL * 64;
-    const bool b16 = ix->dtype == OTTER_BF16;       // stream16_kernel: q16_plane = the queries' bf16 plane (16 columns)
+                        Scratch* sc, const void* q16_plane = nullptr, const void* x16_plane = nullptr) {
+    // x16_plane: a bf16 plane of an OTTER_F32 index (its hi values: the one-product coarse pass of a small batch);
+    // k may then be a coarse k + margin of up to 320, which takes the 768-slot candidate lists
+    const bool b16 = ix->dtype == OTTER_BF16 || x16_plane != nullptr;   // stream16_kernel: q16_plane = the queries' bf16 plane
+    const int EPL = k <= 160 ? 8 : 12, CAP = EPL * 64;
     const int G = nq <= 16 ? (b16 ? 4 : nq <= 4 ? 1 : nq <= 8 ? 2 : 4) : 8;     // query columns / 4
     const int nqp = 4 * G;
     const int total_tiles = (int)((ix->n + ST_BM - 1) / ST_BM);
@@ -2785,7 +2787,7 @@ int search_chunk_stream(otter_index* ix, const float* qd, long long nq, int k, f
                            (long long)nqp, ix->d, ix->ld);
     }
     StreamArgs sa;
-    sa.X = b16 ? (const float*)ix->x16 : ix->x;
+    sa.X = x16_plane ? (const float*)x16_plane : b16 ? (const float*)ix->x16 : ix->x;
     sa.Q = b16 ? (const float*)q16_plane : q_in_place ? qd : (const float*)w_qpad;
     sa.q_rows = q_in_place ? (int)nq : nqp;
     sa.cand = (u64*)w_cand;
@@ -2814,12 +2816,14 @@ int search_chunk_stream(otter_index* ix, const float* qd, long long nq, int k, f
         OTTER_HIP_TRY(hipEventRecord(ev.first, st));
     }
     // (ring depth by LDS: 4 waves x slots x (8 KiB + queries))
-    if (b16 && G <= 4) launch_stream16<1, EPL, 3>(sa, strips, st);
-    else if (b16) launch_stream16<2, EPL, 3>(sa, strips, st);
-    else if (G == 1) launch_stream<1, EPL, 32, 4>(sa, strips, st);
-    else if (G == 2) launch_stream<2, EPL, 32, 4>(sa, strips, st);
-    else if (G == 4) launch_stream<4, EPL, 32, 3>(sa, strips, st);
-    else launch_stream32<EPL, 3>(sa, strips, st);
+    if (b16 && EPL == 12 && G <= 4) launch_stream16<1, 12, 3>(sa, strips, st);
+    else if (b16 && EPL == 12) launch_stream16<2, 12, 3>(sa, strips, st);
+    else if (b16 && G <= 4) launch_stream16<1, 8, 3>(sa, strips, st);
+    else if (b16) launch_stream16<2, 8, 3>(sa, strips, st);
+    else if (G == 1) launch_stream<1, 8, 32, 4>(sa, strips, st);      // (the fp32 kernels serve k <= 128: 512-slot lists)
+    else if (G == 2) launch_stream<2, 8, 32, 4>(sa, strips, st);
+    else if (G == 4) launch_stream<4, 8, 32, 3>(sa, strips, st);
+    else launch_stream32<8, 3>(sa, strips, st);
     OTTER_HIP_TRY(hipGetLastError());
     if (timed) {
         OTTER_HIP_TRY(hipEventRecord(ev.second, st));
@@ -2841,8 +2845,11 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
         // MFMA-bound batches on a large corpus: coarse pass on the bf16 matrix cores + exact re-scoring
         static const char* no_split_env = getenv("OTTER_NO_SPLIT");
         static const char* split_min_env = getenv("OTTER_SPLIT_MIN_NQ");   // tuning runs only
-        static const int split_min = split_min_env ? atoi(split_min_env) : 33;   // above the 32-query tile of the exact kernel, the
-                                                                                 // last one that is HBM-bound (measured: 33..64 queries 1.0 -> 0.7 ms)
+        // Every batch size: from 33 queries on the coarse pass is the 256-query-tile scan on the matrix cores; up to 32
+        // it is ONE read of the bf16 hi plane by the stream kernel -- half the bytes of the fp32 rows the exact stream
+        // kernels read (1M x 768: 1 query 0.50 -> 0.35 ms per call, 32 queries 0.63 -> 0.37).  OTTER_SPLIT_MIN_NQ=33
+        // keeps small batches on the exact fp32 stream kernels (no extra planes in HBM, no read-back per call).
+        static const int split_min = split_min_env ? atoi(split_min_env) : 1;
         static const char* mode_env = getenv("OTTER_SPLIT_MODE");          // "1": three-product coarse pass first
         if (!no_split_env && !ix->no_split && !ix->coarse_off && nq >= split_min && ix->n >= 65536 && split_kc(k, 1, ix->d) <= S16_MAX_K) {
             const int rs = ensure_split_planes(ix, st);
@@ -3279,7 +3286,15 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
         hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0,
                            st, qd, (unsigned short*)ix->qh16.p, nq, nq_pad, ix->d, ix->ld, 0ll);
         OTTER_HIP_TRY(hipGetLastError());
-        rc = scan16_and_merge<0>(ix, ix->xh.p, ix->ld, nq, kc, (float*)ix->cD.p, (long long*)ix->cI.p, st, ix->qh16.p);
+        static const char* no_stream16 = getenv("OTTER_NO_STREAM");
+        if (nq <= 32 && kc <= 320 && !no_stream16) {
+            // a small batch: the coarse pass is one read of the hi plane by the bf16 stream kernel (half the bytes of
+            // the fp32 rows), its kc candidates go through the same re-scoring and proof
+            Scratch own;
+            rc = search_chunk_stream(ix, qd, nq, kc, (float*)ix->cD.p, (long long*)ix->cI.p, st, &own, ix->qh16.p, ix->xh.p);
+        } else {
+            rc = scan16_and_merge<0>(ix, ix->xh.p, ix->ld, nq, kc, (float*)ix->cD.p, (long long*)ix->cI.p, st, ix->qh16.p);
+        }
     } else if (mode == 2)
         rc = scan16_and_merge<2>(ix, ix->xs.p, 2 * ix->ld, nq, kc, (float*)ix->cD.p, (long long*)ix->cI.p, st);
     else

@@ -89,10 +89,10 @@ def corpus_1m():
 
 
 def test_batch_size_ladder_is_one_result(corpus_1m):
-    """configs[2]'s query-batch range on one 1M x 768 fp32 shard: whatever regime serves a batch (stream kernel up to
-    16 queries, 32x32x2 kernel up to 32, coarse bf16 pass + exact re-scoring from 33 on), the rows and scores of a
-    query are the same bits.  Reference = the queries searched 16 at a time (stream kernel); independent arbiter =
-    the oracle's float64 rule on a sample."""
+    """configs[2]'s query-batch range on one 1M x 768 fp32 shard: whatever regime serves a batch (coarse pass by the
+    bf16 stream kernel up to 32 queries, by the 256-query-tile scan from 33 on, exact re-scoring and proof behind both),
+    the rows and scores of a query are the same bits.  Reference = the EXACT fp32 stream kernels (the allocation-free
+    entry point, 16 queries per call); independent arbiter = the oracle's float64 rule on a sample."""
     from otter_amd.index import IndexFlatIP
     xb = corpus_1m
     q = _rows(4096, 97)
@@ -101,8 +101,8 @@ def test_batch_size_ladder_is_one_result(corpus_1m):
     Dr = torch.empty((4096, K), dtype=torch.float32, device="cuda")
     Ir = torch.empty((4096, K), dtype=torch.int64, device="cuda")
     for lo in range(0, 4096, 16):
-        Dr[lo:lo + 16], Ir[lo:lo + 16] = ix.search(q[lo:lo + 16].contiguous(), K)
-    for nq in (1, 8, 17, 32, 33, 64, 256, 4096):
+        ix.search_noalloc(q[lo:lo + 16].contiguous(), K, Dr[lo:lo + 16], Ir[lo:lo + 16])
+    for nq in (1, 8, 16, 17, 32, 33, 64, 256, 4096):
         D, I = ix.search(q[:nq].contiguous(), K)
         assert torch.equal(I, Ir[:nq]), "batch of %d: ids differ from the 16-query calls" % nq
         assert torch.equal(D.view(torch.int32), Dr[:nq].view(torch.int32)), "batch of %d: scores differ" % nq

@@ -25,8 +25,24 @@ def _search(xb, q, k, chunks=1):
         ix.add(part)
     assert ix.ntotal == xb.shape[0]
     D, I = ix.search(q, k)
+    _also_exact_stream_kernels(ix, q, k, D, I)
     ix.close()
     return D, I
+
+
+def _also_exact_stream_kernels(ix, q, k, D, I):
+    """search() serves small batches on a large fp32 corpus with a coarse pass over its bf16 hi plane + exact
+    re-scoring; the allocation-free entry point keeps them on the exact fp32 stream kernels.  Same bits either way."""
+    import torch
+    nq = q.shape[0]
+    if not (1 <= nq <= 32 and k <= 128 and ix.d <= 4096):
+        return
+    qd = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).cuda()
+    De = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    Ie = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    ix.search_noalloc(qd, k, De, Ie)
+    np.testing.assert_array_equal(Ie.cpu().numpy(), np.asarray(I))
+    np.testing.assert_array_equal(De.cpu().numpy().view(np.uint32), np.asarray(D).view(np.uint32))
 
 
 CASES = [
@@ -86,6 +102,7 @@ def test_stream_kernel_survives_a_threshold_that_passes_everything():
     ix = IndexFlatIP(128)
     ix.add(xb)
     D, I = ix.search(q, 100)
+    _also_exact_stream_kernels(ix, q, 100, D, I)
     assert (I == np.arange(100)[None, :]).all()
     assert (D == D[:, :1]).all()
     # the same corpus with one better row far away: it must come first
@@ -93,6 +110,7 @@ def test_stream_kernel_survives_a_threshold_that_passes_everything():
     ix.reset()
     ix.add(xb)
     D, I = ix.search(q, 100)
+    _also_exact_stream_kernels(ix, q, 100, D, I)
     assert I[2, 0] == 299999 and (I[2, 1:] == np.arange(99)).all()
     ix.close()
 
@@ -107,6 +125,7 @@ def test_stream_kernel_repeated_calls_leave_clean_counters():
     ref = {}
     for nq, k in [(1, 100), (16, 10), (5, 128), (1, 1), (9, 64), (1, 100), (16, 10)]:
         D, I = ix.search(q[:nq], k)
+        _also_exact_stream_kernels(ix, q[:nq], k, D, I)
         key = (nq, k)
         if key not in ref:
             Dr, Ir = flat_ip.search_c(xb, q[:nq], k, mode=flat_ip.MODE_GPU_ORDER)
