@@ -1757,7 +1757,8 @@ __global__ void to_bf16_rows_kernel(const float* __restrict__ src, unsigned shor
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, long long sld,
                                                          unsigned short* __restrict__ dst, long long rows,
                                                          long long rows_pad, int d, int ld, float* norm2,
-                                                         long long row0, float* res2 = nullptr) {
+                                                         long long row0, float* res2 = nullptr,
+                                                         unsigned short* __restrict__ hi_only = nullptr) {
     const int lane = threadIdx.x & 63;
     const long long w0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
     const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
@@ -1771,6 +1772,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
             unsigned short* o = dst + plane_index(row0 + r, (c >> 5) * 64 + (c & 31), 2 * ld);   // lo: +32, same slab
             o[0] = __builtin_bit_cast(unsigned short, hi);
             o[32] = __builtin_bit_cast(unsigned short, lo);
+            if (hi_only) hi_only[plane_index(row0 + r, c, ld)] = __builtin_bit_cast(unsigned short, hi);   // (to_bf16_rows_kernel's plane)
             ss += v * v;
         }
         if (norm2) {
@@ -1848,6 +1850,7 @@ struct RescoreArgs {
     u32* out_cnt;          // [S2][nq_pad]
     long long id_base;
     int ld, kc, k, nq_pad;
+    u32* zero_word;        // a counter to leave at zero for the kernel after this one (null: none)
 };
 
 // The candidate rows are gathered through LDS.  Loading the 32x32x2 fragments straight from global memory touches 32
@@ -1937,6 +1940,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             }
         }
     }
+    if (a.zero_word && q == 0 && threadIdx.x == 0) *a.zero_word = 0u;
     // counts: invalid candidates (id < 0) are the tail of the list (one wave counts with ballots)
     if (wave == 0) {
         int valid = 0;
@@ -3269,9 +3273,11 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
     if ((rc = ix->rs.reserve((size_t)S2 * nq_pad * k * sizeof(u64)))) return rc;
     if ((rc = ix->rscnt.reserve((size_t)S2 * nq_pad * sizeof(u32)))) return rc;
     if ((rc = ix->flags.reserve((size_t)(nq + 1) * sizeof(u32)))) return rc;
+    if (mode == 3 && (rc = ix->qh16.reserve((size_t)nq_pad * ix->ld * 2))) return rc;
+    // (one kernel: hi/lo planes, both norms and, for the one-product pass, the hi values alone as a plane of their own)
     hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)std::min<long long>((nq_pad + 3) / 4, 16384)), dim3(256), 0, st,
                        qd, (long long)ix->d, (unsigned short*)ix->qs.p, nq, nq_pad, ix->d, ix->ld, (float*)ix->qnorm2.p,
-                       0ll, (float*)ix->qres2.p);
+                       0ll, (float*)ix->qres2.p, mode == 3 ? (unsigned short*)ix->qh16.p : (unsigned short*)nullptr);
     // the re-scoring reads the fp32 query rows: in place when the caller's rows already have the padded length
     const bool q_in_place = ix->ld == ix->d && ((uintptr_t)qd & 15) == 0;
     if (!q_in_place) {
@@ -3281,11 +3287,6 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
     }
     OTTER_HIP_TRY(hipGetLastError());
     if (mode == 3) {
-        if ((rc = ix->qh16.reserve((size_t)nq_pad * ix->ld * 2))) return rc;
-        const long long total = nq_pad * ix->ld;
-        hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0,
-                           st, qd, (unsigned short*)ix->qh16.p, nq, nq_pad, ix->d, ix->ld, 0ll);
-        OTTER_HIP_TRY(hipGetLastError());
         static const char* no_stream16 = getenv("OTTER_NO_STREAM");
         if (nq <= 32 && kc <= 320 && !no_stream16) {
             // a small batch: the coarse pass is one read of the hi plane by the bf16 stream kernel (half the bytes of
@@ -3311,13 +3312,13 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
     ra.kc = kc;
     ra.k = k;
     ra.nq_pad = (int)nq_pad;
+    ra.zero_word = (u32*)ix->flags.p + nq;        // the margin check's count of unproven queries
     launch_rescore(ra, (unsigned)nq, st);
     OTTER_HIP_TRY(hipGetLastError());
     if ((rc = run_merge(ix, (const u64*)ix->rs.p, (const u32*)ix->rscnt.p, k, S2, nq, nq_pad, k, true, D, I, nullptr,
                         nullptr, nullptr, nullptr, nullptr, st)))
         return rc;
     u32* flags = (u32*)ix->flags.p;
-    OTTER_HIP_TRY(hipMemsetAsync(flags + nq, 0, sizeof(u32), st));
     hipLaunchKernelGGL(margin_check_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (const float*)D,
                        (const float*)ix->cD.p, (const long long*)ix->cI.p, (const float*)ix->qnorm2.p,
                        (const u32*)ix->xnmax.p, split_rel_eps(ix->d), nq, k, kc, ix->n, flags, flags + nq,
@@ -3614,6 +3615,7 @@ int otter_index_search_subset(otter_index* ix, const void* q, int64_t nq, int k,
         ra.kc = m;
         ra.k = k;
         ra.nq_pad = (int)c_pad;
+        ra.zero_word = nullptr;
         launch_rescore(ra, (unsigned)c, st);
         OTTER_HIP_TRY(hipGetLastError());
         if ((rc = run_merge(ix, (const u64*)ix->rs.p, (const u32*)ix->rscnt.p, k, S2, c, c_pad, k, true, Dd, Id, nullptr,

@@ -68,14 +68,18 @@ def main():
         kms = ms / max(n, 1)
         gbs = a.rows * a.dim * (2 if a.dtype == 'bf16' else 4) / (kms * 1e-3) / 1e9
         tf = 2.0 * a.rows * a.dim * nq / (kms * 1e-3) / 1e12
-        # which matrix pipe serves this point: fp32 index, <= 32 queries -> exact fp32 kernels (fp32 matrix peak);
-        # fp32 index, >= 33 queries -> coarse pass on bf16 planes (one product per term: the kernel's flops are
-        # bf16 flops against the bf16 peak; the fp32-equivalent ratio is printed beside it, it is not a roofline)
-        coarse16 = a.dtype == "bf16" or (nq >= 33 and a.rows >= 65536 and not os.environ.get("OTTER_NO_SPLIT"))
+        # which matrix pipe serves this point, and what its scan reads: an fp32 index on a corpus of >= 65,536 rows runs
+        # a coarse pass on the bf16 hi plane (N*d*2 bytes: the stream kernel up to 32 queries, the 256-query-tile scan
+        # above) and re-scores exactly; OTTER_NO_SPLIT=1 / OTTER_SPLIT_MIN_NQ keep batches on the exact fp32 kernels
+        smin = int(os.environ.get("OTTER_SPLIT_MIN_NQ", "1"))
+        coarse16 = a.dtype == "bf16" or (nq >= smin and a.rows >= 65536 and not os.environ.get("OTTER_NO_SPLIT"))
         bytes_per = 2 if a.dtype == "bf16" else 4
+        read_per = 2 if coarse16 else 4
         rec = {"nq": nq, "k": a.k, "rows": a.rows, "scan_ms": round(kms, 4), "wall_ms": round(wall, 4),
                "GBps": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM, 4),
                "hbm_frac_wall": round(a.rows * a.dim * bytes_per / (wall * 1e-3) / 1e9 / PEAK_HBM, 4),
+               "scan_bytes_read": a.rows * a.dim * read_per,
+               "hbm_frac_scan_of_bytes_read": round(a.rows * a.dim * read_per / (kms * 1e-3) / 1e9 / PEAK_HBM, 4),
                "TFLOPs": round(tf, 2),
                "mfma_pipe": "bf16" if coarse16 else "fp32",
                "mfma_frac": round(tf / (2500.0 if coarse16 else PEAK_F32), 4),
