@@ -21,12 +21,13 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the device's default
  *     stream).  Calls with host buffers synchronise the stream before returning.
  *     Calls with device buffers enqueue their work on the stream and return, with
- *     these exceptions, which also wait for it: otter_index_search of 33 and more
- *     queries on an OTTER_F32 index of 65,536 and more rows (one 4-byte read-back
- *     per pass of the coarse search: how many queries still lack a proof; usually
- *     one pass), otter_index_search_subset (validation of the id lists),
- *     otter_index_add when the allocation grows, and otter_index_timing.  A
- *     search of at most 32 queries only enqueues.
+ *     these exceptions, which also wait for it: otter_index_search on an
+ *     OTTER_F32 index of 65,536 and more rows whose coarse-pass planes fit HBM
+ *     (one 4-byte read-back per pass of the coarse search: how many queries still
+ *     lack a proof; usually one pass), otter_index_search_subset (validation of
+ *     the id lists), otter_index_add when the allocation grows, and
+ *     otter_index_timing.  otter_index_search_noalloc, searches of an OTTER_BF16
+ *     index and searches of smaller fp32 indexes only enqueue.
  *   - no torch types anywhere; plain pointers and sizes only.
  */
 #ifndef OTTER_HIP_H
@@ -145,7 +146,7 @@ int otter_index_set_timing(otter_index* ix, int enable);
 int otter_index_timing(otter_index* ix, double* scan_ms, int64_t* scan_launches);
 
 /* State of the coarse pass of an index (no counterpart in the reference): 0 = its bf16 planes are not built yet
- * (they are built by the first search of 33 and more queries: once the corpus' bytes again for the hi/lo planes,
+ * (they are built by the first search: once the corpus' bytes again for the hi/lo planes,
  * half of them again for the one-product plane), 1 = built and in use, 2 = HBM had no room for them, so the exact
  * fp32 kernel serves every batch size (about 1/6 of the rate at 2,214 queries; a note goes to stderr once),
  * 3 = not an OTTER_F32 index, 4 = switched off for this corpus until reset(): even the three-product pass left more

@@ -4,8 +4,8 @@ Mirrors `index = faiss.IndexFlatIP(d); index.add(xb); D, I = index.search(q, k)`
 (reference scripts/eval_ottqa_retrieval.py:108-109,129): same names, same argument
 meaning, same result layout (D float32 [nq, k] descending, I int64 [nq, k], -1 padding).
 numpy in -> numpy out (host copies); torch device tensors in -> torch device tensors
-out (zero copy; work is enqueued on the current stream -- a search of 33 and more queries also
-waits for it once per pass of the coarse search, see include/otter_hip.h).
+out (zero copy; work is enqueued on the current stream -- a search of an fp32 index of 65,536 and
+more rows also waits for it once per pass of its coarse search, see include/otter_hip.h).
 
 All compute happens in libotter_hip.so (otter_amd/csrc/index.hip); there is no CPU path.
 """
