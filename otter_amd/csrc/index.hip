@@ -1851,6 +1851,7 @@ struct RescoreArgs {
     long long id_base;
     int ld, kc, k, nq_pad;
     u32* zero_word;        // a counter to leave at zero for the kernel after this one (null: none)
+    int wg_per_q;          // workgroups that share a query's candidates (few queries: spread them over more CUs)
 };
 
 // The candidate rows are gathered through LDS.  Loading the 32x32x2 fragments straight from global memory touches 32
@@ -1864,7 +1865,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     extern __shared__ __attribute__((aligned(16))) char rsm[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = (int)(blockDim.x >> 6);
-    const int q = blockIdx.x;
+    const int q = blockIdx.x / a.wg_per_q, part = blockIdx.x - q * a.wg_per_q;
     const int h = lane >> 5, l31 = lane & 31;
     const float* qrow = a.Q + (size_t)q * a.ld;
     char* wbuf = rsm + wave * 8192;                       // [2][32 rows][128 B]
@@ -1876,7 +1877,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     }
     const int S = a.ld / 32;                              // steps of 32 floats (ld is a multiple of 64: S is even)
     const int lr = lane >> 3, lc = lane & 7;              // this lane's row within an instruction's 8, its 16-byte chunk
-    for (int c0 = wave * 32; c0 < a.kc; c0 += nw * 32) {
+    for (int c0 = (part * nw + wave) * 32; c0 < a.kc; c0 += a.wg_per_q * nw * 32) {
         const int ci = c0 + l31;
         const long long id = ci < a.kc ? a.Ic[(size_t)q * a.kc + ci] : -1ll;
         const long long row = id >= 0 ? id - a.id_base : 0;
@@ -1940,9 +1941,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             }
         }
     }
-    if (a.zero_word && q == 0 && threadIdx.x == 0) *a.zero_word = 0u;
+    if (a.zero_word && blockIdx.x == 0 && threadIdx.x == 0) *a.zero_word = 0u;
     // counts: invalid candidates (id < 0) are the tail of the list (one wave counts with ballots)
-    if (wave == 0) {
+    if (wave == 0 && part == 0) {
         int valid = 0;
         for (int i0 = 0; i0 < a.kc; i0 += 64) {
             const int i = i0 + lane;
@@ -1960,12 +1961,23 @@ void launch_rescore(const RescoreArgs& ra, unsigned grid, hipStream_t st) {
     const size_t qbytes = (size_t)ra.ld * 4;
     const bool qlds = qbytes <= 32768;
     const int max_w = qlds ? std::min(8, (int)((65536 - qbytes) / 8192)) : 8;
-    const int groups = std::max(1, (ra.kc + 31) / 32), rounds = (groups + max_w - 1) / max_w;
-    const int nw = (groups + rounds - 1) / rounds;
+    const int groups = std::max(1, (ra.kc + 31) / 32);
+    RescoreArgs a2 = ra;
+    int nw;
+    if ((long long)grid * groups <= 1024) {
+        // few queries: one wave per workgroup, a query's groups spread over as many CUs (1 query x 211 candidates:
+        // one workgroup took 28 us, latency-bound on its one CU)
+        a2.wg_per_q = groups;
+        nw = 1;
+    } else {
+        const int rounds = (groups + max_w - 1) / max_w;
+        a2.wg_per_q = 1;
+        nw = (groups + rounds - 1) / rounds;
+    }
     if (qlds)
-        hipLaunchKernelGGL(rescore_lds_kernel<true>, dim3(grid), dim3(64 * nw), (size_t)nw * 8192 + qbytes, st, ra);
+        hipLaunchKernelGGL(rescore_lds_kernel<true>, dim3(grid * a2.wg_per_q), dim3(64 * nw), (size_t)nw * 8192 + qbytes, st, a2);
     else
-        hipLaunchKernelGGL(rescore_lds_kernel<false>, dim3(grid), dim3(64 * nw), (size_t)nw * 8192, st, ra);
+        hipLaunchKernelGGL(rescore_lds_kernel<false>, dim3(grid * a2.wg_per_q), dim3(64 * nw), (size_t)nw * 8192, st, a2);
 }
 
 // A query's exact top k is proven complete when its k-th exact score exceeds every score a row
@@ -2855,7 +2867,11 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
         // keeps small batches on the exact fp32 stream kernels (no extra planes in HBM, no read-back per call).
         static const int split_min = split_min_env ? atoi(split_min_env) : 1;
         static const char* mode_env = getenv("OTTER_SPLIT_MODE");          // "1": three-product coarse pass first
-        if (!no_split_env && !ix->no_split && !ix->coarse_off && nq >= split_min && ix->n >= 65536 && split_kc(k, 1, ix->d) <= S16_MAX_K) {
+        // (a small batch pays about 60 us for the re-scoring, the proof and its read-back: worth it once the half
+        // plane it saves is a few hundred megabytes -- 1M x 768 saves 1.5 GB = 0.15 ms; below, the exact stream kernels)
+        const bool small_ok = nq > 32 || (!split_min_env && (long long)ix->n * ix->ld >= 200000000ll) || (split_min_env != nullptr);
+        if (!no_split_env && !ix->no_split && !ix->coarse_off && nq >= split_min && small_ok && ix->n >= 65536 &&
+            split_kc(k, 1, ix->d) <= S16_MAX_K) {
             const int rs = ensure_split_planes(ix, st);
             if (rs < 0) return rs;
             if (rs == 0) {
