@@ -2883,7 +2883,11 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
                     if (rh < 0) return rh;
                     if (rh == 0) mode = 3;
                 }
-                return search_chunk_split(ix, qd, nq, k, D, I, st, mode, true);
+                // (a small batch gains only from the one-product pass on the hi plane, which the bf16 stream kernel
+                // reads once; without it -- no room for that plane, or a corpus that needs more products -- the exact
+                // stream kernels below are at least as fast as a 256-query-tile scan with 1 ... 32 real columns)
+                if (nq > 32 || k > 128 || (mode == 3 && split_kc(k, 3, ix->d) <= 320))
+                    return search_chunk_split(ix, qd, nq, k, D, I, st, mode, true);
             }
         }
     }
