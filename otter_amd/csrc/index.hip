@@ -3353,9 +3353,11 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
     OTTER_HIP_TRY(hipStreamSynchronize(st));
     const long long nf = *ix->h_flag;
     if (mode >= 2 && first) ix->last_refined += nf;
-    if (mode == 3 && nf * 4 > nq) ix->one_prod_off = true;
-    if (mode == 2 && nf * 4 > nq) ix->two_prod_off = true;
-    if (mode == 1 && nf * 4 > nq) {
+    // (a verdict on the corpus needs a batch worth the name: one hard query of a one-query call is not one)
+    const bool verdict = nq >= 32 && nf * 4 > nq;
+    if (mode == 3 && verdict) ix->one_prod_off = true;
+    if (mode == 2 && verdict) ix->two_prod_off = true;
+    if (mode == 1 && verdict) {
         if (!ix->coarse_off)
             fprintf(stderr, "[libotter_hip] note: the coarse pass could not prove %lld of %lld queries on this index (scores closer "
                             "than bf16 products resolve); batches are served by the exact fp32 kernel until reset() "
