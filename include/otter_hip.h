@@ -173,6 +173,22 @@ int64_t otter_index_last_refined(const otter_index* index);
 int otter_merge_topk(int device, const float* Dc, const int64_t* Ic, int G, int64_t nq, int k,
                      float* D, int64_t* I, void* stream);
 
+/* index = faiss.index_cpu_to_all_gpus(index); index.search(q, k) -- scripts/eval_ottqa_retrieval.py:110-112,129:
+ * ONE process driving every GPU.  (The reference replicates the whole index on each GPU; here the rows are
+ * sharded, so G GPUs hold G times the corpus and each query reads every row once.)
+ * shards[0..G): indexes created on their own devices (several may share a device), each holding a contiguous
+ * row range with otter_index_set_id_base(first global row).  q, D, I as in otter_index_search: all host
+ * pointers, or all device pointers on the device of shards[0] (the "home" GPU; `stream` is a stream there).
+ * Every shard is searched from its own host thread on its own stream (a search may wait for its GPU, and the
+ * GPUs must not wait for each other); queries and candidates travel as peer copies (xGMI), 12 bytes per
+ * candidate; the G-way merge (otter_merge_topk, hierarchical past G * k = 8192) runs on the home GPU.  No
+ * communicator is involved: inside one process peer copies need none.  The multi-process form (one rank per
+ * GPU, RCCL all-gather of the packed candidates) is otter_amd/sharded.py over otter_index_search and
+ * otter_merge_topk.  The call waits for `stream` and for every shard before it returns.  G <= 64.
+ * Not thread-safe per handle, like every call here: one otter_sharded_search at a time per set of shards. */
+int otter_sharded_search(otter_index* const* shards, int G, const void* q, int64_t nq, int k,
+                         float* D, int64_t* I, int io_is_device, void* stream);
+
 /* In-batch score matrix of the fine-tuning script's dev-set evaluation (reference
  * scripts/train_1hop_tb_retrieval.py:304-319; the same matrix is the input of loss_single,
  * retrieval/criterions.py:15-17): product[i][j] = q_i . c_j for j < B and, when neg_c is given,

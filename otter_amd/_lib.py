@@ -53,6 +53,7 @@ SIGNATURES = {
     "otter_index_destroy": (None, [c_vp]),
     "otter_index_set_timing": (c_int, [c_vp, c_int]),
     "otter_index_timing": (c_int, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
+    "otter_sharded_search": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_int, c_vp]),
     "otter_merge_topk": (c_int, [c_int, c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp]),
     "otter_inbatch_scores": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     "otter_encoder_create": (c_int, [ctypes.POINTER(EncoderCfg), c_int, ctypes.POINTER(c_vp)]),

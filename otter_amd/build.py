@@ -17,7 +17,7 @@ OBJDIR = os.path.join(_PKG, "csrc", "_obj")
 SOURCES = ["common.hip", "index.hip", "encoder.hip", "gemm_bf16.hip"]
 HEADERS = ["otter_common.h", "otter_device.h", "otter_gemm.h", os.path.join("..", "..", "include", "otter_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-Wall", "-Wno-unused-function",
          "-Rpass-analysis=kernel-resource-usage"]
 # Kernels that load into REGISTERS from inline asm and wait for them by hand (counted vmcnt): the register allocator
 # does not know the destination is still in flight, so a spill there is not just slow -- it may reuse a register an
@@ -92,7 +92,7 @@ def build_lib(force=False, verbose=True):
         if slow and verbose:
             print("[otter_amd.build] note: spills in hot kernels: %s" % ", ".join(slow), file=sys.stderr)
     if force or procs or _mtime(LIB) < max(_mtime(o) for o in objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs
         if verbose:
             print("[otter_amd.build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)

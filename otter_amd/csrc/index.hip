@@ -20,6 +20,8 @@
 
 #include <algorithm>
 #include <new>
+#include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -2618,6 +2620,10 @@ struct otter_index {
     u32* h_flag = nullptr;          // pinned word for the one read-back of a coarse pass
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
+    // otter_sharded_search: this shard's own stream and staging (queries in, candidates out); on shards[0] also
+    // the gathered candidates of every shard and the levels of a hierarchical merge
+    hipStream_t sh_stream = nullptr;
+    otter::DevBuf sh_q, sh_D, sh_I, sh_gD, sh_gI, sh_tD, sh_tI;
 };
 
 // Scratch of otter_index_search_noalloc (include/otter_hip.h): one fixed region per GPU, part of the code
@@ -3783,6 +3789,8 @@ void otter_index_destroy(otter_index* ix) {
     ix->io_D.release();
     ix->io_I.release();
     if (ix->h_flag) (void)hipHostFree(ix->h_flag);
+    if (ix->sh_stream) (void)hipStreamDestroy(ix->sh_stream);
+    for (otter::DevBuf* b : {&ix->sh_q, &ix->sh_D, &ix->sh_I, &ix->sh_gD, &ix->sh_gI, &ix->sh_tD, &ix->sh_tI}) b->release();
     delete ix;
 }
 
@@ -3814,6 +3822,136 @@ int otter_merge_topk(int device, const float* Dc, const int64_t* Ic, int G, int6
     }
     hipLaunchKernelGGL(pair_merge_kernel, dim3((unsigned)nq), dim3(NTHREADS), lds, (hipStream_t)stream, a);
     OTTER_HIP_TRY(hipGetLastError());
+    return OTTER_OK;
+}
+
+// One shard's part of otter_sharded_search, on its own host thread: queries to the shard's GPU, search on the
+// shard's stream, candidates into slot g of the gathered buffers on the home GPU; returns once they have landed.
+static int sharded_search_one(otter_index* ix, int home, const void* q, int q_is_device, int64_t nq, int k, float* gD,
+                              long long* gI) {
+    DeviceGuard g(ix->device);
+    if (!g.ok) return set_err(OTTER_EHIP, "sharded_search: hipSetDevice(%d) failed", ix->device);
+    if (!ix->sh_stream) OTTER_HIP_TRY(hipStreamCreateWithFlags(&ix->sh_stream, hipStreamNonBlocking));
+    hipStream_t st = ix->sh_stream;
+    const size_t qbytes = (size_t)nq * ix->d * sizeof(float), nk = (size_t)nq * k;
+    int rc;
+    const float* qd = (const float*)q;
+    if (!q_is_device) {
+        if ((rc = ix->sh_q.reserve(qbytes))) return rc;
+        OTTER_HIP_TRY(hipMemcpyAsync(ix->sh_q.p, q, qbytes, hipMemcpyHostToDevice, st));
+        qd = (const float*)ix->sh_q.p;
+    } else if (ix->device != home) {
+        if ((rc = ix->sh_q.reserve(qbytes))) return rc;
+        OTTER_HIP_TRY(hipMemcpyPeerAsync(ix->sh_q.p, ix->device, q, home, qbytes, st));
+        qd = (const float*)ix->sh_q.p;
+    }
+    if (ix->device == home) {
+        // same GPU as the gathered buffers: the search writes its slot directly
+        if ((rc = otter_index_search(ix, qd, nq, k, gD, (int64_t*)gI, 1, st))) return rc;
+    } else {
+        if ((rc = ix->sh_D.reserve(nk * sizeof(float)))) return rc;
+        if ((rc = ix->sh_I.reserve(nk * sizeof(long long)))) return rc;
+        if ((rc = otter_index_search(ix, qd, nq, k, (float*)ix->sh_D.p, (int64_t*)ix->sh_I.p, 1, st))) return rc;
+        OTTER_HIP_TRY(hipMemcpyPeerAsync(gD, home, ix->sh_D.p, ix->device, nk * sizeof(float), st));
+        OTTER_HIP_TRY(hipMemcpyPeerAsync(gI, home, ix->sh_I.p, ix->device, nk * sizeof(long long), st));
+    }
+    OTTER_HIP_TRY(hipStreamSynchronize(st));
+    return OTTER_OK;
+}
+
+int otter_sharded_search(otter_index* const* shards, int G, const void* q, int64_t nq, int k, float* D, int64_t* I,
+                         int io_is_device, void* stream) {
+    if (!shards || G < 1 || G > 64) return set_err(OTTER_EINVAL, "sharded_search: need 1 ... 64 shards (G=%d)", G);
+    for (int g = 0; g < G; ++g) {
+        if (!shards[g]) return set_err(OTTER_EINVAL, "sharded_search: shard %d is NULL", g);
+        if (shards[g]->d != shards[0]->d)
+            return set_err(OTTER_EINVAL, "sharded_search: shard %d has d=%d, shard 0 has d=%d", g, shards[g]->d, shards[0]->d);
+        for (int h = 0; h < g; ++h)
+            if (shards[h] == shards[g]) return set_err(OTTER_EINVAL, "sharded_search: shards %d and %d are the same index", h, g);
+    }
+    if (nq < 0) return set_err(OTTER_EINVAL, "sharded_search: nq=%lld < 0", (long long)nq);
+    if (k < 1 || k > OTTER_MAX_K) return set_err(OTTER_EINVAL, "sharded_search: k=%d outside [1, %d]", k, OTTER_MAX_K);
+    if (nq == 0) return OTTER_OK;
+    if (!q || !D || !I) return set_err(OTTER_EINVAL, "sharded_search: q, D and I must be non-NULL");
+    otter_index* h0 = shards[0];
+    const int home = h0->device;
+    DeviceGuard guard(home);
+    if (!guard.ok) return set_err(OTTER_EHIP, "sharded_search: hipSetDevice(%d) failed", home);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nk = (size_t)nq * k;
+    int rc;
+    if (G == 1) return otter_index_search(h0, q, nq, k, D, I, io_is_device, stream);
+    if ((rc = h0->sh_gD.reserve((size_t)G * nk * sizeof(float)))) return rc;
+    if ((rc = h0->sh_gI.reserve((size_t)G * nk * sizeof(long long)))) return rc;
+    // peer copies go GPU to GPU over xGMI where the pair allows it (otherwise HIP stages them through the host)
+    for (int g = 1; g < G; ++g) {
+        const int dv = shards[g]->device;
+        int can = 0;
+        if (dv != home && hipDeviceCanAccessPeer(&can, home, dv) == hipSuccess && can) {
+            (void)hipDeviceEnablePeerAccess(dv, 0);          // "already enabled" is fine
+            (void)hipGetLastError();
+            DeviceGuard pg(dv);
+            if (pg.ok) { (void)hipDeviceEnablePeerAccess(home, 0); (void)hipGetLastError(); }
+        }
+    }
+    // device queries: whatever produces them on the caller's stream has to be done before other GPUs read them
+    if (io_is_device) OTTER_HIP_TRY(hipStreamSynchronize(st));
+    // one host thread per shard: a search may wait for its GPU (proof read-back), and the GPUs must not wait
+    // for each other
+    std::vector<int> rcs((size_t)G, OTTER_OK);
+    std::vector<std::string> msgs((size_t)G);
+    auto run = [&](int g) {
+        rcs[g] = sharded_search_one(shards[g], home, q, io_is_device, nq, k, (float*)h0->sh_gD.p + (size_t)g * nk,
+                                    (long long*)h0->sh_gI.p + (size_t)g * nk);
+        if (rcs[g]) msgs[g] = otter::err_buf();
+    };
+    {
+        std::vector<std::thread> th;
+        th.reserve((size_t)G - 1);
+        for (int g = 1; g < G; ++g) th.emplace_back(run, g);
+        run(0);
+        for (auto& t : th) t.join();
+    }
+    for (int g = 0; g < G; ++g)
+        if (rcs[g]) return set_err(rcs[g], "sharded_search: shard %d (device %d): %s", g, shards[g]->device, msgs[g].c_str());
+    // G-way merge on the home GPU, hierarchical when G * k exceeds one workgroup's select
+    float* oD = D;
+    int64_t* oI = I;
+    if (!io_is_device) {
+        if ((rc = h0->io_D.reserve(nk * sizeof(float)))) return rc;
+        if ((rc = h0->io_I.reserve(nk * sizeof(long long)))) return rc;
+        oD = (float*)h0->io_D.p;
+        oI = (int64_t*)h0->io_I.p;
+    }
+    const float* cD = (const float*)h0->sh_gD.p;
+    const int64_t* cI = (const int64_t*)h0->sh_gI.p;
+    int lists = G;
+    const int step = std::max(2, MAX_SELECT / k);
+    if (lists > step) {
+        const size_t lvl = (size_t)((lists + step - 1) / step) * nk;
+        if ((rc = h0->sh_tD.reserve(lvl * sizeof(float)))) return rc;
+        if ((rc = h0->sh_tI.reserve(lvl * sizeof(long long)))) return rc;
+    }
+    while (lists > step) {
+        // groups of `step` lists -> one list each: merged into the level buffer, then copied back to the front of
+        // the gathered buffer, which the next round (or the final merge) reads
+        const int groups = (lists + step - 1) / step;
+        for (int j = 0; j < groups; ++j) {
+            const int g0 = j * step, gn = std::min(step, lists - g0);
+            if ((rc = otter_merge_topk(home, cD + (size_t)g0 * nk, cI + (size_t)g0 * nk, gn, nq, k,
+                                       (float*)h0->sh_tD.p + (size_t)j * nk, (int64_t*)h0->sh_tI.p + (size_t)j * nk, stream)))
+                return rc;
+        }
+        OTTER_HIP_TRY(hipMemcpyAsync(h0->sh_gD.p, h0->sh_tD.p, (size_t)groups * nk * sizeof(float), hipMemcpyDeviceToDevice, st));
+        OTTER_HIP_TRY(hipMemcpyAsync(h0->sh_gI.p, h0->sh_tI.p, (size_t)groups * nk * sizeof(long long), hipMemcpyDeviceToDevice, st));
+        lists = groups;
+    }
+    if ((rc = otter_merge_topk(home, cD, cI, lists, nq, k, oD, oI, stream))) return rc;
+    if (!io_is_device) {
+        OTTER_HIP_TRY(hipMemcpyAsync(D, oD, nk * sizeof(float), hipMemcpyDeviceToHost, st));
+        OTTER_HIP_TRY(hipMemcpyAsync(I, oI, nk * sizeof(long long), hipMemcpyDeviceToHost, st));
+    }
+    OTTER_HIP_TRY(hipStreamSynchronize(st));
     return OTTER_OK;
 }
 

@@ -85,9 +85,15 @@ def load_id2doc(path):
 
 
 def build_index(xb, d=None, devices=None):
-    """scripts/eval_ottqa_retrieval.py:108-113: IndexFlatIP(d); add(xb).  xb may be a numpy memmap."""
-    from .index import IndexFlatIP
+    """scripts/eval_ottqa_retrieval.py:108-113: IndexFlatIP(d); add(xb) and, with --gpu,
+    faiss.index_cpu_to_all_gpus(index) -- here the rows go straight to their GPUs (row shards, one process:
+    index.MultiGpuIndexFlatIP).  xb may be a numpy memmap."""
+    from .index import IndexFlatIP, MultiGpuIndexFlatIP
     d = xb.shape[1] if d is None else d
+    if devices and len(devices) > 1:
+        index = MultiGpuIndexFlatIP(d, devices=devices)
+        index.add(xb)
+        return index
     index = IndexFlatIP(d, device=0 if not devices else devices[0])
     step = 1 << 18                       # add in slabs: a memmapped .npy never has to fit in host memory
     for lo in range(0, xb.shape[0], step):
@@ -163,6 +169,9 @@ def main(argv=None):
     ap.add_argument("--faiss_save_path", type=str, default="",
                     help="flat IndexFlatIP file: read instead of building when it exists (scripts/eval_ottqa_retrieval.py:106-107)")
     ap.add_argument("--eval_only_ans", action="store_true")
+    ap.add_argument("--gpu", action="store_true",
+                    help="every visible GPU, as scripts/eval_ottqa_retrieval.py:110-112 (rows sharded, not replicated); "
+                         "without it: GPU 0")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO)
     with open(args.raw_data_path, "r", encoding="utf8") as f:
@@ -174,7 +183,11 @@ def main(argv=None):
         from .index_io import read_index
         index = read_index(args.faiss_save_path)
     else:
-        index = build_index(xb)
+        devices = None
+        if args.gpu:
+            from . import _lib
+            devices = list(range(int(_lib.load().otter_device_count())))
+        index = build_index(xb, devices=devices)
     id2doc = load_id2doc(args.id2doc_path)
     D, I = index.search(q, args.beam_size)          # one batched call (the reference: nq = 1 per call, 24 processes)
     index.close()

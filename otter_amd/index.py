@@ -266,6 +266,114 @@ class IndexFlatIP:
             pass
 
 
+class MultiGpuIndexFlatIP:
+    """One process, every GPU: what `index = faiss.index_cpu_to_all_gpus(index)` gives the reference
+    (scripts/eval_ottqa_retrieval.py:110-112), with the rows SHARDED over the devices instead of replicated.
+
+    devices: HIP ordinals, one shard each (default: every visible GPU; an ordinal may repeat -- several shards
+    on one GPU, which is how the one-GPU tests drive it).  Shard g holds rows [g*ceil(N/G), ...) of the array
+    handed to add(); ids are insertion order.  search(): numpy in -> numpy out, or tensors on devices[0] in ->
+    tensors there out.  All compute and the exchange are otter_sharded_search (include/otter_hip.h)."""
+
+    def __init__(self, d, devices=None, dtype="fp32"):
+        self._lib = _lib.load()
+        if devices is None:
+            devices = list(range(int(self._lib.otter_device_count())))
+        devices = [int(x) for x in devices]
+        if not devices:
+            raise ValueError("MultiGpuIndexFlatIP: no devices")
+        self.d, self.dtype, self.devices = int(d), dtype, devices
+        self.shards = [IndexFlatIP(d, device=dv, dtype=dtype) for dv in devices]
+        self._handles = (ctypes.c_void_p * len(self.shards))(*[s._h for s in self.shards])
+        self._added = False
+
+    @property
+    def ntotal(self):
+        return sum(s.ntotal for s in self.shards)
+
+    @property
+    def is_trained(self):
+        return True
+
+    def add(self, x):
+        """index.add(xb), once: rows are cut into len(devices) contiguous ranges (numpy / memmap / CPU tensor, or a
+        tensor on any GPU -- each range is copied to its shard's device)."""
+        if self._added:
+            raise RuntimeError("MultiGpuIndexFlatIP.add: rows are sharded by contiguous ranges; add once (or reset() first)")
+        n, G = int(x.shape[0]), len(self.shards)
+        per = -(-n // G) if n else 0
+        for g, sh in enumerate(self.shards):
+            lo, hi = min(n, g * per), min(n, (g + 1) * per)
+            sh.set_id_base(lo)
+            for a in range(lo, hi, 1 << 18):          # slab by slab: a memmapped .npy never has to fit in host memory
+                part = x[a:min(hi, a + (1 << 18))]
+                if _is_torch(part) and part.is_cuda and part.device.index != sh.device:
+                    part = part.to("cuda:%d" % sh.device)
+                sh.add(part)
+        self._added = True
+
+    def reset(self):
+        for sh in self.shards:
+            sh.reset()
+        self._added = False
+
+    def search(self, q, k):
+        k = int(k)
+        if k < 1 or k > _lib.OTTER_MAX_K:
+            raise ValueError("search: k=%d outside [1, %d]" % (k, _lib.OTTER_MAX_K))
+        home = self.devices[0]
+        if _is_torch(q) and q.is_cuda:
+            if q.dim() != 2 or q.shape[1] != self.d or q.device.index != home:
+                raise ValueError("search: expected [nq, %d] on device %d, got %r on %s" % (self.d, home, tuple(q.shape), q.device))
+            q = q.to(torch.float32).contiguous()
+            nq = q.shape[0]
+            D = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+            _lib.check(self._lib.otter_sharded_search(self._handles, len(self.shards), ctypes.c_void_p(q.data_ptr()), nq, k,
+                                                      ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()), 1,
+                                                      _stream_ptr(home)), "otter_sharded_search")
+            return D, I
+        if _is_torch(q):
+            q = q.detach().numpy()
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self.d:
+            raise ValueError("search: expected [nq, %d] float32, got %r" % (self.d, q.shape))
+        nq = q.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        _lib.check(self._lib.otter_sharded_search(self._handles, len(self.shards), ctypes.c_void_p(q.ctypes.data), nq, k,
+                                                  ctypes.c_void_p(D.ctypes.data), ctypes.c_void_p(I.ctypes.data), 0,
+                                                  _stream_ptr(home)), "otter_sharded_search")
+        return D, I
+
+    def close(self):
+        for sh in self.shards:
+            sh.close()
+
+
+def index_cpu_to_all_gpus(index, devices=None):
+    """faiss.index_cpu_to_all_gpus(index) (scripts/eval_ottqa_retrieval.py:112): spread a filled IndexFlatIP over
+    `devices` (default: every visible GPU) as a MultiGpuIndexFlatIP; the rows leave the source index slab by slab
+    (reconstruct_n) and the source is closed.  One device: the index is returned as it is."""
+    lib = _lib.load()
+    if devices is None:
+        devices = list(range(int(lib.otter_device_count())))
+    if len(devices) == 1 and int(devices[0]) == index.device:
+        return index
+    n, G = index.ntotal, len(devices)
+    multi = MultiGpuIndexFlatIP(index.d, devices=devices, dtype=index.dtype)
+    per = -(-n // G) if n else 0
+    slab = 1 << 18
+    for g, sh in enumerate(multi.shards):
+        lo, hi = min(n, g * per), min(n, (g + 1) * per)
+        sh.set_id_base(lo)
+        for a in range(lo, hi, slab):
+            sh.add(index.reconstruct_n(a, min(slab, hi - a)))
+    multi._added = True
+    index.close()
+    return multi
+
+
 def merge_topk(Dc, Ic, device=None):
     """Merge G per-shard results: Dc float32 [G, nq, k], Ic int64 [G, nq, k] (torch, on one
     GPU) -> (D [nq, k], I [nq, k]).  Hierarchical when G*k exceeds one workgroup's select."""
