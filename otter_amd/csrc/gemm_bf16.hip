@@ -14,9 +14,11 @@
 //   * LDS holds two K-steps, each as four 16 KiB half-tiles in the order they are consumed:
 //     A-first (token rows of quadrant row 0 of both groups), B-first (feature rows of quadrant
 //     column 0 of all four waves), B-second, A-second.  One half-tile is DMA'd per phase
-//     (global_load_lds_dwordx4, 2 per wave), seven half-tiles ahead of the consumer, across output
-//     tiles (the stream of K-steps is flat over this workgroup's tiles), and retired with a
-//     counted s_waitcnt vmcnt(8): four half-tiles stay in flight, the loop never drains to zero.
+//     (global_load_lds_dwordx4, 2 per wave, issued between the two halves of the phase's MFMA segment,
+//     where a piece costs less issue time than in a load segment), seven half-tiles ahead of the
+//     consumer, across output tiles (the stream of K-steps is flat over this workgroup's tiles), and
+//     retired in the load segments with a counted s_waitcnt vmcnt(6): three half-tiles stay in flight,
+//     the loop never drains to zero.
 //   * Fragments are read from LDS one phase before the MFMAs that use them (a load segment only
 //     issues reads and DMA; the counted lgkmcnt lands inside the MFMA segment).
 //   * 128-byte LDS rows, 16-B chunks XOR-swizzled through the DMA *source* address
@@ -28,8 +30,9 @@
 // Hazard bookkeeping (segments are the intervals between barriers; group 1 is one behind):
 //   RAW  a half-tile retired by the wait in segment j is read no earlier than segment j + 2;
 //   WAR  a slot is refilled no earlier than 3 segments after the MFMA segment that consumed it.
-// With half-tile h = 4u + p + 7 issued in load phase p of K-step u, and the wait of that phase
-// covering everything up to 4u + p + 3, both hold by construction (table in DESIGN.md §4).
+// With half-tile h = 4u + p + 7 issued in the MFMA segment of phase p of K-step u (one segment later than
+// the load segment that used to issue it: WAR only gains), and the wait of load phase p covering everything
+// up to 4u + p + 3, both hold by construction (table in DESIGN.md §4).
 //
 // LayerNorm folded around the GEMM (template parameter LN, GemmLN in otter_gemm.h): the producer
 // (residual epilogue) stores the un-normalised sum and per-row (sum, sum of squares) partials of
@@ -281,11 +284,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
             Wf[nq][nb][1] = *reinterpret_cast<const float4*>(base + wrow + nb * 2048 + coff1);
         }
     };
-    auto mma = [&](float4 (&X)[4][2], int mq, int nq) {
+    bool last_issued = false;
+    auto mma = [&](float4 (&X)[4][2], int mq, int nq, int kind) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -293,29 +297,34 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
                     acc[4 * mq + mb][2 * nq + nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8, Wf[nq][nb][ks]), __builtin_bit_cast(bf16x8, X[mb][ks]),
                         acc[4 * mq + mb][2 * nq + nb], 0, 0, 0);
+            // the phase's half-tile is issued between the two halves of the MFMA segment: a DMA piece costs about
+            // 60 cycles of issue here against 100 and more in a load segment, and the load segment is the longer one
+            if (ks == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+#if !defined(GEMM_ABL) || GEMM_ABL != 1
+                last_issued = issue(kind);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
     // `after_store`: the tile epilogue's 16 stores per lane sit inside the window of the four
     // youngest half-tiles for the next three phases; allow them to stay outstanding too
     DG(unsigned long long dW = 0, dI = 0;)
-    auto stage_and_wait = [&](int kind, bool after_store) {
+    // Load-segment wait of phase p of K-step u: half-tile 4u + p + 3 has landed once at most the three younger ones
+    // (6 pieces) are outstanding; `after_store`: a tile's stores (and the row statistics) sit among them for the four
+    // phases after an epilogue and may stay outstanding too.  Anything else in flight only makes the wait stricter.
+    DG(unsigned long long dW = 0, dI = 0;)
+    auto wait_landed = [&](bool after_store) {
         DG(unsigned long long tw0 = stamp();)
-#if defined(GEMM_ABL) && GEMM_ABL == 1
-        const bool issued = true;
-#else
-        const bool issued = issue(kind);
-#endif
-        DG(unsigned long long tw1 = stamp(); dI += tw1 - tw0;)
 #if !defined(GEMM_ABL) || GEMM_ABL != 2
-        if (issued) {
-            if (after_store) wait_vmcnt<8 + EPI_STORES>();
-            else wait_vmcnt<8>();
-        } else {
-            wait_vmcnt<0>();
-        }
+        if (!last_issued) wait_vmcnt<0>();
+        else if (after_store) wait_vmcnt<6 + EPI_STORES>();
+        else wait_vmcnt<6>();
 #endif
-        DG(dW += stamp() - tw1;)
+        DG(dW += stamp() - tw0;)
     };
     auto epilogue = [&]() {
         const int col0 = c_tn * 256 + wn * 64 + 8 * (fq >> 1) + 16 * (fq & 1);
@@ -440,7 +449,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
     issue_rowstat(c_tm);
     issue(0); issue(1); issue(2); issue(3);
     issue(0); issue(1);
-    if (issue(2)) wait_vmcnt<8>();   // A-first(0), B-first(0), B-second(0) have landed
+    last_issued = issue(2);
+    if (last_issued) wait_vmcnt<8>();   // A-first(0), B-first(0), B-second(0) have landed
     else wait_vmcnt<0>();
     __syncthreads();                 // ... for every wave; the bias vector is in LDS
     init_acc();
@@ -450,33 +460,33 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
     // Fragments are read from LDS one phase before the MFMAs that use them, so a load segment only
     // issues its reads (their latency passes under the other group's MFMAs and this group's own);
     // the one exception is W0, which phase 3 still uses when the next K-step begins.
-    // Segment (u, p) issues half-tile 4u + p + 7 and then waits until 4u + p + 3 has landed.
+    // Load segment (u, p) waits until half-tile 4u + p + 3 has landed; MFMA segment (u, p) issues 4u + p + 7.
     for (int cs = 0; cs < total_stages; ++cs) {
         const char* lb = smem + (cs & 1) * BUF;
         const bool as = c_t == 0 && cs > 0;   // first K-step after an epilogue
         // phase 0: quadrant (0, 0)
         ldW(0, lb + OFF_BF);
         ldW(1, lb + OFF_BS);
-        stage_and_wait(3, as);
+        wait_landed(as);
         barA();
-        mma(X0, 0, 0);
+        mma(X0, 0, 0, 3);
         barB();
         // phase 1: quadrant (0, 1)
         ldX(X1, lb + OFF_AS);
-        stage_and_wait(0, as);
+        wait_landed(as);
         barA();
-        mma(X0, 0, 1);
+        mma(X0, 0, 1, 0);
         barB();
         // phase 2: quadrant (1, 1); token fragments of the next K-step's quadrant row 0
         if (cs + 1 < total_stages) ldX(X0, smem + ((cs + 1) & 1) * BUF + OFF_AF);
-        stage_and_wait(1, as);
+        wait_landed(as);
         barA();
-        mma(X1, 1, 1);
+        mma(X1, 1, 1, 1);
         barB();
         // phase 3: quadrant (1, 0)
-        stage_and_wait(2, false);
+        wait_landed(as);
         barA();
-        mma(X1, 1, 0);
+        mma(X1, 1, 0, 2);
         if (++c_t == KT) {
             // both groups write their tile in the same barrier interval
             c_t = 0;
