@@ -284,6 +284,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
             Wf[nq][nb][1] = *reinterpret_cast<const float4*>(base + wrow + nb * 2048 + coff1);
         }
     };
+    DG(unsigned long long dW = 0, dI = 0;)
     bool last_issued = false;
     auto mma = [&](float4 (&X)[4][2], int mq, int nq, int kind) {
         __builtin_amdgcn_sched_barrier(0);
@@ -302,7 +303,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
             if (ks == 0) {
                 __builtin_amdgcn_sched_barrier(0);
 #if !defined(GEMM_ABL) || GEMM_ABL != 1
+                DG(unsigned long long ti0 = stamp();)
                 last_issued = issue(kind);
+                DG(dI += stamp() - ti0;)
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -312,11 +315,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(PPArgs a) {
     };
     // `after_store`: the tile epilogue's 16 stores per lane sit inside the window of the four
     // youngest half-tiles for the next three phases; allow them to stay outstanding too
-    DG(unsigned long long dW = 0, dI = 0;)
     // Load-segment wait of phase p of K-step u: half-tile 4u + p + 3 has landed once at most the three younger ones
     // (6 pieces) are outstanding; `after_store`: a tile's stores (and the row statistics) sit among them for the four
     // phases after an epilogue and may stay outstanding too.  Anything else in flight only makes the wait stricter.
-    DG(unsigned long long dW = 0, dI = 0;)
     auto wait_landed = [&](bool after_store) {
         DG(unsigned long long tw0 = stamp();)
 #if !defined(GEMM_ABL) || GEMM_ABL != 2
