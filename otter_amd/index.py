@@ -321,6 +321,8 @@ class MultiGpuIndexFlatIP:
         k = int(k)
         if k < 1 or k > _lib.OTTER_MAX_K:
             raise ValueError("search: k=%d outside [1, %d]" % (k, _lib.OTTER_MAX_K))
+        if self._handles is None:
+            raise RuntimeError("MultiGpuIndexFlatIP.search: the index was closed")
         home = self.devices[0]
         if _is_torch(q) and q.is_cuda:
             if q.dim() != 2 or q.shape[1] != self.d or q.device.index != home:
@@ -347,6 +349,7 @@ class MultiGpuIndexFlatIP:
         return D, I
 
     def close(self):
+        self._handles = None          # (the array holds copies of the shards' handles)
         for sh in self.shards:
             sh.close()
 

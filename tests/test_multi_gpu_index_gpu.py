@@ -78,6 +78,9 @@ def test_index_cpu_to_all_gpus_moves_the_rows():
     assert np.array_equal(I1, Im) and np.array_equal(D1, Dm)
     with pytest.raises(RuntimeError):
         multi.add(x)
+    multi.close()
+    with pytest.raises(RuntimeError):
+        multi.search(q, 10)
     same = IndexFlatIP(d)
     assert index_cpu_to_all_gpus(same, devices=[0]) is same
 
