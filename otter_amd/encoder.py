@@ -316,6 +316,78 @@ class _EncoderBase:
     __call__ = forward
 
 
+class DataParallel:
+    """model = torch.nn.DataParallel(model) of scripts/encode_corpus.py:112-113: ONE process, a batch cut along its
+    first dimension over the GPUs, results gathered on device_ids[0].  nn.DataParallel broadcasts the weights and
+    rebuilds its replicas on every call; here each GPU keeps its own resident copy (built on first use from the
+    module's host weights) and a call only moves the token tensors out and the embeddings back.  Every replica's
+    forward is only enqueued on its GPU's current stream, so the GPUs run side by side under one host thread.
+
+    device_ids: HIP ordinals (default: every visible GPU); an ordinal may repeat (the one-GPU tests).  The object
+    has the module's surface (`eval()`, `forward(batch)`, `module`, `device_index` = device_ids[0]), so
+    encode_driver.predict pipelines it like a single encoder.  One process per GPU instead: sharded.encode_rows."""
+
+    def __init__(self, module, device_ids=None):
+        if device_ids is None:
+            device_ids = list(range(torch.cuda.device_count()))
+        device_ids = [int(d) for d in device_ids]
+        if not device_ids:
+            raise ValueError("DataParallel: no devices")
+        self.module = module
+        self.device_ids = device_ids
+        self.device_index = device_ids[0]
+        module.to("cuda:%d" % device_ids[0])
+        self.replicas = [module]
+        for d in device_ids[1:]:
+            r = type(module)(module.config, module.args, device="cuda:%d" % d, dtype=module.dtype)
+            r._weights = module._weights            # the same host tensors: no copy until the replica's first call
+            self.replicas.append(r)
+        self.training = False
+
+    def eval(self):
+        for r in self.replicas:
+            r.eval()
+        return self
+
+    def to(self, device):
+        if torch.device(device).index not in (None, self.device_ids[0]):
+            raise RuntimeError("DataParallel: the replicas stay on device_ids; results are gathered on cuda:%d" % self.device_ids[0])
+        return self
+
+    def state_dict(self):
+        return OrderedDict(("module." + k, v) for k, v in self.module.state_dict().items())
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Keys with or without nn.DataParallel's `module.` prefix; every replica is rebuilt on its next call."""
+        sd = OrderedDict((k[7:] if k.startswith("module.") else k, v) for k, v in state_dict.items())
+        res = self.module.load_state_dict(sd, strict=strict)
+        for r in self.replicas[1:]:
+            r._weights = self.module._weights
+            r._release()
+        return res
+
+    def forward(self, batch):
+        first = next(t for t in batch.values() if torch.is_tensor(t))
+        B = int(first.shape[0])
+        G = len(self.replicas)
+        per = -(-B // G)                                 # nn.DataParallel's scatter: chunks of ceil(B / G)
+        outs = []
+        for g, r in enumerate(self.replicas):
+            lo, hi = g * per, min(B, (g + 1) * per)
+            if hi <= lo:
+                break
+            dev = torch.device("cuda", self.device_ids[g])
+            sub = {k: (v[lo:hi].to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+            with torch.cuda.device(dev):
+                outs.append(r(sub)["embed"])
+        home = torch.device("cuda", self.device_ids[0])
+        if len(outs) == 1:
+            return {"embed": outs[0].to(home)}
+        return {"embed": torch.cat([o.to(home, non_blocking=True) for o in outs], dim=0)}
+
+    __call__ = forward
+
+
 class SingleEncoderThreeCatPool(_EncoderBase):
     """retrieval/models/tb_retriever.py:150-227 (BERT family: token types, arange positions)."""
     three_cat, roberta = True, False
