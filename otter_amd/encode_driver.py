@@ -8,6 +8,7 @@ Unlike the reference (its `try/except ... continue`, :138-143) a failing batch r
 batch would silently shift every later row against id2doc.json
 (retrieval/data/encode_datasets.py:145-152).
 """
+import json
 import os
 
 import numpy as np
@@ -230,3 +231,139 @@ def em_collate_bert(samples, pad_id=0):
         if src in samples[0]["tb"]:
             batch[dst] = collate_tokens([s["tb"][src].view(-1) for s in samples], 0)
     return batch
+
+
+# ------------------------------------------------------------------ the script: scripts/encode_corpus.py:25-123
+def load_records(path, table, allow_pickle=False):
+    """The reference reads questions from JSON and the corpus from a pickle of records whose `table` is a pandas
+    DataFrame (retrieval/data/encode_datasets.py:128-136).  Here: .json (a list) or .jsonl (one record per line; a
+    record's `table` is then [header, [[row]]], the form id2doc.json holds); a .pkl corpus is read only on request
+    (allow_pickle: unpickling executes what the file says, so it must be the caller's own file)."""
+    ext = os.path.splitext(path)[1].lower()
+    if ext in (".pkl", ".pickle"):
+        if not allow_pickle:
+            raise ValueError("%s is a pickle; pass --allow_pickle for a file you wrote yourself, or convert it to .jsonl" % path)
+        import pickle
+        with open(path, "rb") as f:
+            return pickle.load(f)
+    with open(path, "r", encoding="utf-8") as f:
+        if ext == ".jsonl":
+            return [json.loads(line) for line in f if line.strip()]
+        return json.load(f)
+
+
+def build_model(bert_config, args, dtype=None):
+    """The class choice of scripts/encode_corpus.py:48-69."""
+    from . import encoder as E
+    roberta = "roberta" in args.model_name
+    if args.three_cat:
+        if args.part_pooling[:3] == "att":
+            cls = E.RobertaSingleEncoderThreeCatAtt if roberta else E.SingleEncoderThreeCatAtt
+        else:
+            cls = E.RobertaSingleEncoderThreeCatPool if roberta else E.SingleEncoderThreeCatPool
+    else:
+        cls = E.RobertaSingleEncoder if roberta else E.SingleEncoder
+    return cls(bert_config, args, dtype=dtype)
+
+
+def encode_args(argv=None):
+    """The arguments of retrieval/config.py:encode_args that the encode path reads (same names and defaults;
+    --metadata / --three_cat / --no_proj / --normalize_table are always-true switches there, kept so)."""
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--predict_file", type=str, required=True)
+    ap.add_argument("--model_name", type=str, default="roberta-base", help="HF name or local directory (config + tokenizer)")
+    ap.add_argument("--init_checkpoint", type=str, required=True)
+    ap.add_argument("--embed_save_path", type=str, required=True)
+    ap.add_argument("--encode_table", action="store_true")
+    ap.add_argument("--predict_batch_size", type=int, default=512)
+    ap.add_argument("--num_workers", type=int, default=0)
+    ap.add_argument("--max_c_len", type=int, default=512)
+    ap.add_argument("--max_q_len", type=int, default=70)
+    ap.add_argument("--psg_mode", type=str, default="ori")
+    ap.add_argument("--no_passages", action="store_true")
+    ap.add_argument("--fp16", action="store_true", help="bf16 weights and activations (the reference: apex amp O1)")
+    ap.add_argument("--shared_encoder", action="store_true")
+    ap.add_argument("--part_pooling", type=str, default="first")
+    ap.add_argument("--metadata", action="store_true", default=True)
+    ap.add_argument("--three_cat", action="store_true", default=True)
+    ap.add_argument("--no_proj", action="store_true", default=True)
+    ap.add_argument("--normalize_table", action="store_true", default=True)
+    ap.add_argument("--one_query", action="store_true", default=True)
+    ap.add_argument("--one_vector", dest="three_cat", action="store_false", help="768-d encoders (RobertaSingleEncoder / SingleEncoder)")
+    ap.add_argument("--no_cuda", action="store_true", help="refused: there is no CPU path")
+    ap.add_argument("--local_rank", type=int, default=-1)
+    ap.add_argument("--allow_pickle", action="store_true")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    """python -m otter_amd.encode_driver ... = scripts/encode_corpus.py: tokenizer and config from --model_name,
+    EmDatasetMetaThreeCat over --predict_file, the encoder class the flags select, load_saved(--init_checkpoint),
+    every visible GPU from one process (encoder.DataParallel) unless launched one process per GPU (RANK / WORLD_SIZE
+    set: sharded.encode_rows, one shard file per rank), predict(), np.save(--embed_save_path) and, for --encode_table,
+    <embed_save_path>/id2doc.json (retrieval/data/encode_datasets.py:141-154)."""
+    import logging
+    from functools import partial
+
+    from torch.utils.data import DataLoader
+    from transformers import AutoConfig, AutoTokenizer
+
+    from . import encoder as E
+    from . import features as F
+    logging.basicConfig(level=logging.INFO)
+    log = logging.getLogger("otter_amd.encode_driver")
+    args = encode_args(argv)
+    if args.no_cuda or not torch.cuda.is_available():
+        raise RuntimeError("otter_amd encodes on the GPU only (no CPU fallback)")
+    bert_config = AutoConfig.from_pretrained(args.model_name)
+    tokenizer = AutoTokenizer.from_pretrained(args.model_name)
+    collate_fc = partial(em_collate_bert, pad_id=tokenizer.pad_token_id)
+    model = build_model(bert_config, args)
+    log.info("Model Using %s...", type(model).__name__)
+    data = load_records(args.predict_file, args.encode_table, args.allow_pickle)
+    log.info("Total sample count %d", len(data))
+    if not args.three_cat:
+        raise NotImplementedError("the script's dataset for the 768-d encoders (EmDatasetMeta) is not built; the encoders are")
+    model = E.load_saved(model, args.init_checkpoint, exact=False)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+
+        from . import sharded
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        if not dist.is_initialized():
+            dist.init_process_group(backend="nccl")
+        model.to("cuda:%d" % local)
+
+        def batches(lo, hi):
+            ds = F.EmDatasetMetaThreeCat(tokenizer, data[lo:hi], args.encode_table, args)
+            return DataLoader(ds, batch_size=args.predict_batch_size, collate_fn=collate_fc, num_workers=args.num_workers)
+        embeds, lo, counts = sharded.encode_rows(model, batches, len(data), to_cpu=True)
+        F.write_embedding_shards(args.embed_save_path, embeds, lo, world, dist.get_rank())
+        log.info("rank %d wrote rows [%d, %d) of %d", dist.get_rank(), lo, lo + embeds.shape[0], len(data))
+        if dist.get_rank() == 0 and args.encode_table:
+            F.write_id2doc(os.path.join(args.embed_save_path, "id2doc.json"), data)
+        return 0
+    n_gpu = torch.cuda.device_count()
+    model.to("cuda:0")
+    if n_gpu > 1:
+        model = E.DataParallel(model)
+    ds = F.EmDatasetMetaThreeCat(tokenizer, data, args.encode_table, args)
+    loader = DataLoader(ds, batch_size=args.predict_batch_size, collate_fn=collate_fc, pin_memory=True,
+                        num_workers=args.num_workers)
+    if args.encode_table:
+        id2doc_path = os.path.join(args.embed_save_path, "id2doc.json")
+        if not os.path.exists(id2doc_path):
+            F.write_id2doc(id2doc_path, data)
+            log.info("Dumping id2doc to %s", id2doc_path)
+    embeds = predict(model, loader)
+    log.info("%s", tuple(embeds.shape))
+    log.info("saving to :%s", args.embed_save_path)
+    save_embeddings(args.embed_save_path if args.embed_save_path.endswith(".npy") else args.embed_save_path + ".npy", embeds)
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
