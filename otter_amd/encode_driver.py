@@ -299,7 +299,7 @@ def encode_args(argv=None):
 
 def main(argv=None):
     """python -m otter_amd.encode_driver ... = scripts/encode_corpus.py: tokenizer and config from --model_name,
-    EmDatasetMetaThreeCat over --predict_file, the encoder class the flags select, load_saved(--init_checkpoint),
+    EmDatasetMetaThreeCat (EmDatasetMeta with --one_vector) over --predict_file, the encoder class the flags select, load_saved(--init_checkpoint),
     every visible GPU from one process (encoder.DataParallel) unless launched one process per GPU (RANK / WORLD_SIZE
     set: sharded.encode_rows, one shard file per rank), predict(), np.save(--embed_save_path) and, for --encode_table,
     <embed_save_path>/id2doc.json (retrieval/data/encode_datasets.py:141-154)."""
@@ -323,8 +323,7 @@ def main(argv=None):
     log.info("Model Using %s...", type(model).__name__)
     data = load_records(args.predict_file, args.encode_table, args.allow_pickle)
     log.info("Total sample count %d", len(data))
-    if not args.three_cat:
-        raise NotImplementedError("the script's dataset for the 768-d encoders (EmDatasetMeta) is not built; the encoders are")
+    Dataset = F.EmDatasetMetaThreeCat if args.three_cat else F.EmDatasetMeta      # scripts/encode_corpus.py:80-86
     model = E.load_saved(model, args.init_checkpoint, exact=False)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
@@ -338,7 +337,7 @@ def main(argv=None):
         model.to("cuda:%d" % local)
 
         def batches(lo, hi):
-            ds = F.EmDatasetMetaThreeCat(tokenizer, data[lo:hi], args.encode_table, args)
+            ds = Dataset(tokenizer, data[lo:hi], args.encode_table, args)
             return DataLoader(ds, batch_size=args.predict_batch_size, collate_fn=collate_fc, num_workers=args.num_workers)
         embeds, lo, counts = sharded.encode_rows(model, batches, len(data), to_cpu=True)
         F.write_embedding_shards(args.embed_save_path, embeds, lo, world, dist.get_rank())
@@ -350,7 +349,7 @@ def main(argv=None):
     model.to("cuda:0")
     if n_gpu > 1:
         model = E.DataParallel(model)
-    ds = F.EmDatasetMetaThreeCat(tokenizer, data, args.encode_table, args)
+    ds = Dataset(tokenizer, data, args.encode_table, args)
     loader = DataLoader(ds, batch_size=args.predict_batch_size, collate_fn=collate_fc, pin_memory=True,
                         num_workers=args.num_workers)
     if args.encode_table:

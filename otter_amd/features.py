@@ -6,7 +6,8 @@ forward consumes.
     get_passages                       utils/common.py:151-161
     three-part mask rule               retrieval/data/tr_dataset.py:117-153 (question branch :125-133,
                                        block branch :139-149)
-    dataset item                       retrieval/data/encode_datasets.py:228-256 (<= 8 passages, '?' stripped)
+    dataset item                       retrieval/data/encode_datasets.py:228-256 (<= 8 passages, '?' stripped);
+                                       :191-226 + tr_dataset.py:58-81 for the 768-d encoders
     id2doc.json                        retrieval/data/encode_datasets.py:141-154
     corpus record                      preprocessing/corpus_preprocess.py:203-221
     collate                            otter_amd.encode_driver.em_collate_bert (encode_datasets.py:393-417)
@@ -127,6 +128,29 @@ def convert_tb_to_features_bert_metadata_threecat_one_query(passages, table, met
     return out
 
 
+def convert_tb_to_features_bert_metadata(passages, table, meta_data, tokenizer, args, encode=False):
+    """retrieval/data/tr_dataset.py:58-81 (the 768-d encoders' features: no part masks):
+    {input_ids, attention_mask[, token_type_ids], length}, [1, L] int64 each."""
+    if table_is_empty(table):
+        if isinstance(passages, str):
+            passage_str = passages
+        elif isinstance(passages, list):
+            passage_str = " ".join(passages)
+        else:
+            raise TypeError("type passages: {}, {}, {}, {}".format(type(passages), passages, table, meta_data))
+        inputs = _encode_plus(tokenizer, passage_str, max_length=args.max_q_len, add_special_tokens=True,
+                              padding="max_length", return_tensors="pt", truncation=True, return_length=True)
+    else:
+        if getattr(args, "normalize_table", True):
+            table_str, passage_str = convert_tb_to_string_metadata_norm(table, passages, meta_data)
+        else:
+            table_str, passage_str = convert_tb_to_string_metadata(table, passages, meta_data)
+        inputs = _encode_plus(tokenizer, table_str, text_pair=passage_str, max_length=args.max_c_len,
+                              add_special_tokens=True, padding="max_length", return_tensors="pt", truncation=True,
+                              return_length=True)
+    return {k: v for k, v in inputs.items()}
+
+
 # ------------------------------------------------------------------ dataset
 class EmDatasetMetaThreeCat:
     """retrieval/data/encode_datasets.py:228-256 (+ processing_data :128-155) without pickle: the corpus is
@@ -157,6 +181,25 @@ class EmDatasetMetaThreeCat:
                 question = question[:-1]
             tb = convert_tb_to_features_bert_metadata_threecat_one_query(question, None, meta_data=None,
                                                                          tokenizer=self.tokenizer, args=self.args)
+        return {"tb": tb}
+
+
+class EmDatasetMeta(EmDatasetMetaThreeCat):
+    """retrieval/data/encode_datasets.py:191-226: the dataset of the 768-d encoders (RobertaSingleEncoder /
+    SingleEncoder, scripts/encode_corpus.py:84-86): same strings, <= 8 passages, no part masks."""
+
+    def __getitem__(self, index):
+        js = self.data[index]
+        if self.table:
+            psg = get_passages(js, getattr(self.args, "psg_mode", "ori"), neg=False)[:8]
+            tb = convert_tb_to_features_bert_metadata(psg, js["table"], js["meta_data"], tokenizer=self.tokenizer,
+                                                      args=self.args)
+        else:
+            question = js["question"]
+            if question.endswith("?"):
+                question = question[:-1]
+            tb = convert_tb_to_features_bert_metadata(question, None, meta_data=None, tokenizer=self.tokenizer,
+                                                      args=self.args)
         return {"tb": tb}
 
 

@@ -53,6 +53,24 @@ def test_feature_builder_and_collate_match_reference(feats, tokenizer):
             assert got == case["strings"]
 
 
+def test_one_vector_dataset_matches_reference(feats, tokenizer):
+    """EmDatasetMeta (the 768-d encoders' dataset) against the reference's own, same inputs
+    (oracle/gen_host_goldens_meta.py -> tests/golden/host_features_meta.json)."""
+    from types import SimpleNamespace
+    with open(os.path.join(GOLD, "host_features_meta.json")) as f:
+        meta = json.load(f)
+    assert len(meta["cases"]) == 6
+    for case in meta["cases"]:
+        args = SimpleNamespace(max_c_len=case["max_c_len"], max_q_len=case["max_q_len"],
+                               normalize_table=case["normalize_table"], no_passages=False, psg_mode="ori")
+        data = feats["corpus"] if case["table"] else feats["questions"]
+        ds = F.EmDatasetMeta(tokenizer, data, case["table"], args)
+        batch = em_collate_bert([ds[i] for i in range(len(ds))], pad_id=tokenizer.pad_token_id)
+        assert set(batch) == set(case["batch"]) == {"input_ids", "input_mask"}
+        for k, v in case["batch"].items():
+            assert torch.equal(batch[k], torch.tensor(v)), (k, case["max_c_len"], case["table"])
+
+
 def test_mask_rule_on_synthetic_special_token_masks():
     # <s> A A A </s> </s> B B </s> <pad> <pad>: part2 = tokens of A, part3 = tokens of B (SURVEY.md §8 a-2m)
     stm = [1, 0, 0, 0, 1, 1, 0, 0, 1, 1, 1]
@@ -190,3 +208,32 @@ def test_index_file_round_trip_and_validation(tmp_path):
             IO.read_flat(p)
     IO.write_index(Fake(x[:0]), p)
     assert IO.read_flat(p)[1].shape == (0, 24)
+
+
+def test_encode_script_arguments_and_class_choice(tmp_path):
+    """encode_driver: argument names / defaults of retrieval/config.py:encode_args, the class choice of
+    scripts/encode_corpus.py:48-69, and the record readers (no GPU involved)."""
+    from otter_amd import encode_driver as ED
+    from otter_amd import encoder as E
+    a = ED.encode_args(["--predict_file", "p", "--init_checkpoint", "c", "--embed_save_path", "e"])
+    assert (a.max_c_len, a.max_q_len, a.predict_batch_size, a.part_pooling, a.psg_mode) == (512, 70, 512, "first", "ori")
+    assert a.three_cat and a.no_proj and a.normalize_table and a.metadata and not a.encode_table and not a.shared_encoder
+    cfg = dict(vocab_size=64, hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128,
+               max_position_embeddings=66, type_vocab_size=1, pad_token_id=1, layer_norm_eps=1e-5)
+    from types import SimpleNamespace
+    hf = SimpleNamespace(**cfg)
+    for name, extra, cls in (("x/roberta-base", [], E.RobertaSingleEncoderThreeCatPool),
+                             ("bert-base-uncased", [], E.SingleEncoderThreeCatPool),
+                             ("roberta-base", ["--part_pooling", "att_self_pool"], E.RobertaSingleEncoderThreeCatAtt),
+                             ("roberta-base", ["--one_vector"], E.RobertaSingleEncoder),
+                             ("bert-base-uncased", ["--one_vector"], E.SingleEncoder)):
+        a = ED.encode_args(["--predict_file", "p", "--init_checkpoint", "c", "--embed_save_path", "e", "--model_name", name] + extra)
+        assert type(ED.build_model(hf, a)) is cls
+    recs = [{"question": "a b?"}, {"question": "c"}]
+    with open(tmp_path / "q.json", "w") as f:
+        json.dump(recs, f)
+    with open(tmp_path / "q.jsonl", "w") as f:
+        f.write("\n".join(json.dumps(r) for r in recs) + "\n\n")
+    assert ED.load_records(str(tmp_path / "q.json"), False) == recs == ED.load_records(str(tmp_path / "q.jsonl"), False)
+    with pytest.raises(ValueError):
+        ED.load_records(str(tmp_path / "corpus.pkl"), True)
