@@ -101,12 +101,36 @@ def build_index(xb, d=None, devices=None):
     return index
 
 
+def tfidf_subsets(ds_items, id2doc, tfidf_qid2docs, topk_doc=20):
+    """retrieval/eval_ottqa_retrieval_tfidffilter.py:486-493 (`mapping`): per question, the rows whose block belongs to
+    one of its first `topk_doc` TF-IDF documents, in id2doc order -- as row-id lists for IndexFlatIP.search_subsets.
+    The reference scans the whole id2doc per question and copies the rows' embeddings into a dict it pickles; here
+    one pass builds table_id -> rows and nothing is copied (the corpus is already resident in the index)."""
+    by_table = collections.defaultdict(list)
+    for idx in range(len(id2doc)):
+        by_table[id2doc[str(idx)]["table_id"]].append(idx)
+    subsets = []
+    for item in ds_items:
+        docs = set(tfidf_qid2docs[item["question_id"]]["doc_ids"][:topk_doc])
+        subsets.append(np.array(sorted(r for t in docs for r in by_table.get(t, ())), dtype=np.int64))
+    return subsets
+
+
+def filtered_search(index, q, beam_size, subsets):
+    """:530-546: the reference builds a throw-away IndexFlatIP over each question's rows and searches it with that one
+    question; here ONE batched call on the resident corpus (otter_index_search_subset).  Returns I [nq, beam] of ROW
+    ids (-1 padded when a question has fewer rows than beam): id2doc[str(row)] is the block the reference would
+    have found at qid2tb[qid][str(position)]."""
+    D, I = index.search_subsets(q, beam_size, subsets, return_positions=False)
+    return D, I
+
+
 def records(ds_items, I, id2doc, beam_size, eval_only_ans=False, with_outputs=True, tokenizer=None):
     """The per-question body of `searching` (:131-154) for a whole batch of result ids I [nq, beam]."""
     tokenizer = tokenizer or SimpleTokenizer()
     metrics, outputs = [], []
     for idx in range(len(I)):
-        topk_tbs = [id2doc[str(int(tb_id))] for tb_id in I[idx]]
+        topk_tbs = [id2doc[str(int(tb_id))] for tb_id in I[idx] if int(tb_id) != -1]   # (-1: fewer rows than beam, tfidffilter:552-555)
         metric_i, output_i = {}, {}
         item = ds_items[idx]
         if eval_only_ans:
@@ -169,6 +193,10 @@ def main(argv=None):
     ap.add_argument("--faiss_save_path", type=str, default="",
                     help="flat IndexFlatIP file: read instead of building when it exists (scripts/eval_ottqa_retrieval.py:106-107)")
     ap.add_argument("--eval_only_ans", action="store_true")
+    ap.add_argument("--tfidf_result_file", type=str, default=None,
+                    help="{question_id: {'doc_ids': [table ids]}}: search each question only among the blocks of its first "
+                         "--topk_doc documents (retrieval/eval_ottqa_retrieval_tfidffilter.py)")
+    ap.add_argument("--topk_doc", type=int, default=20)
     ap.add_argument("--gpu", action="store_true",
                     help="every visible GPU, as scripts/eval_ottqa_retrieval.py:110-112 (rows sharded, not replicated); "
                          "without it: GPU 0")
@@ -184,12 +212,17 @@ def main(argv=None):
         index = read_index(args.faiss_save_path)
     else:
         devices = None
-        if args.gpu:
+        if args.gpu and not args.tfidf_result_file:      # (the filtered script itself uses one GPU, tfidffilter:537-541)
             from . import _lib
             devices = list(range(int(_lib.load().otter_device_count())))
         index = build_index(xb, devices=devices)
     id2doc = load_id2doc(args.id2doc_path)
-    D, I = index.search(q, args.beam_size)          # one batched call (the reference: nq = 1 per call, 24 processes)
+    if args.tfidf_result_file:
+        with open(args.tfidf_result_file, "r", encoding="utf8") as f:
+            tfidf_qid2docs = json.load(f)
+        D, I = filtered_search(index, q, args.beam_size, tfidf_subsets(ds_items, id2doc, tfidf_qid2docs, args.topk_doc))
+    else:
+        D, I = index.search(q, args.beam_size)      # one batched call (the reference: nq = 1 per call, 24 processes)
     index.close()
     metrics, outputs = records(ds_items, I, id2doc, args.beam_size, args.eval_only_ans, args.output_save_path != "")
     if args.output_save_path:
