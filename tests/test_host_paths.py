@@ -237,3 +237,21 @@ def test_encode_script_arguments_and_class_choice(tmp_path):
     assert ED.load_records(str(tmp_path / "q.json"), False) == recs == ED.load_records(str(tmp_path / "q.jsonl"), False)
     with pytest.raises(ValueError):
         ED.load_records(str(tmp_path / "corpus.pkl"), True)
+
+
+def test_tfidf_subsets_follow_the_reference_mapping(feats):
+    """eval_driver.tfidf_subsets = `mapping` of retrieval/eval_ottqa_retrieval_tfidffilter.py:486-493: the rows whose
+    table_id is among the first topk_doc TF-IDF documents of the question, in id2doc order."""
+    from otter_amd import eval_driver as EV
+    corpus, questions = feats["corpus"], feats["questions"]
+    id2doc = {str(k): v for k, v in F.id2doc_from_corpus(corpus).items()}
+    tables = sorted({c["table_id"] for c in corpus})
+    tfidf = {qd["question_id"]: {"doc_ids": [tables[(2 * i + j) % len(tables)] for j in range(5)] + ["absent"]}
+             for i, qd in enumerate(questions)}
+    for topk in (1, 3, 6):
+        subs = EV.tfidf_subsets(questions, id2doc, tfidf, topk)
+        assert len(subs) == len(questions)
+        for qd, sub in zip(questions, subs):
+            docs = set(tfidf[qd["question_id"]]["doc_ids"][:topk])
+            within = [int(idx) for idx, doc in id2doc.items() if doc["table_id"] in docs]     # the reference's scan
+            assert sub.dtype == np.int64 and sub.tolist() == within
