@@ -635,9 +635,402 @@ __global__ __launch_bounds__(1024 / QB, QB == 2 ? 2 : 4) void attn_full_kernel(A
     }
 }
 
+// ------------------------------------------------------------------ attention, bf16, software-pipelined
+// One 256-thread workgroup per (batch, head), ONE wave per SIMD with the whole 512-register file; all K and V of
+// the head resident in LDS as in attn_full_kernel (same image, same fill, same store).  A wave owns four 32-query
+// blocks, interleaved over the waves (wave w: blocks w, w + 4, w + 8, w + 12, so that short sequences load every
+// SIMD alike).  The unit of work is one 32-query block against one 64-key tile; units are walked tile-major
+// (u = 4 t + block) and the steps of a unit are spread over three consecutive stages, so that ONE stage (one basic
+// block, 16 slots of one MFMA + a slice of vector work each, hand-ordered and pinned with sched_barrier) holds
+//     the score products of unit u + 1          (8 MFMAs, 8 K fragment reads; accumulators start from the key bias)
+//     the context products of unit u - 1        (8 MFMAs, 16 transposed V reads)
+//     exponentials, row sums, bf16 packing of u (vector ALU)
+// i.e. the matrix pipe and the vector ALU always have independent work from the same instruction stream, and the
+// loop has no branch but its own.
+// Per score the vector ALU does one v_exp, one add and half a packed convert; nothing else:
+//   * the scale: the query rows arrive pre-multiplied by (1/8) log2(e) -- folded into W_q / b_q at finalize;
+//   * the key-padding bias is the INITIAL VALUE of the score accumulators (read from LDS straight into them);
+//   * no running maximum: softmax is invariant under a per-row factor -- p = 2^s and the row sum carry the same
+//     one -- and fp32 / bf16 hold 2^-126 .. 2^127, while scores of a trained encoder are a few tens at most.
+//     Instead of watching the maximum, the RESULT is checked: a block of queries is accepted iff every row sum
+//     lies in (1e-30, 1e30) (then no exponential overflowed, no context sum can have, and nothing underflowed);
+//     otherwise -- scores beyond +-100, or rows with every key masked -- the wave recomputes that block with a
+//     plain online-softmax loop (attn_block_safe below; slow, exact, never taken on sane inputs).
+// Wait until all but the youngest 4 * nt vector-memory operations of this wave are done (nt = 1 .. 8) and only then
+// let the compiler see the query registers as written.  ONE statement on purpose: the wait and the "written now"
+// fence cannot be separated, and there is one set of tied operands (a switch over eight statements made hipcc copy
+// the registers in front of the waits, i.e. read them before the loads had landed).  The query fragments live in
+// accumulator registers: only MFMAs read them.
+__device__ __forceinline__ void wait_q_landed(f32x4v (&q)[4][4], int nt) {
+    asm volatile(
+        "s_waitcnt vmcnt(32)\n\t"
+        "s_cmp_ge_u32 %16, 8\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(28)\n\t"
+        "s_cmp_ge_u32 %16, 7\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(24)\n\t"
+        "s_cmp_ge_u32 %16, 6\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(20)\n\t"
+        "s_cmp_ge_u32 %16, 5\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(16)\n\t"
+        "s_cmp_ge_u32 %16, 4\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(12)\n\t"
+        "s_cmp_ge_u32 %16, 3\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(8)\n\t"
+        "s_cmp_ge_u32 %16, 2\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(4)\n"
+        "1:"
+        : "+a"(q[0][0]), "+a"(q[0][1]), "+a"(q[0][2]), "+a"(q[0][3]), "+a"(q[1][0]), "+a"(q[1][1]), "+a"(q[1][2]),
+          "+a"(q[1][3]), "+a"(q[2][0]), "+a"(q[2][1]), "+a"(q[2][2]), "+a"(q[2][3]), "+a"(q[3][0]), "+a"(q[3][1]),
+          "+a"(q[3][2]), "+a"(q[3][3])
+        : "s"(nt)
+        : "memory", "scc");
+}
+
+// The score products are written as asm: hipcc selects ONE register class for the accumulators of every MFMA builtin
+// of a kernel, and in a 512-register kernel that is the accumulator file -- right for the context accumulators (only
+// MFMAs touch them), wrong for the scores, which the vector ALU reads: every score would be copied out with
+// v_accvgpr_read.  Here: D = C in arch VGPRs, A (keys) in arch VGPRs, B (queries) in the accumulator file.
+// hipcc pads no hazard of an asm statement.  In front: C comes from an LDS read or the previous product of the
+// chain, A from an LDS read, B was written at kernel entry: nothing to pad.  Behind: this MFMA's D must not be read
+// by the vector ALU for 12 wait states (8-pass MFMA); in the pipelined loop the first reader is a whole stage away
+// (order pinned by sched_barrier), elsewhere scores_ready() stands between.
+__device__ __forceinline__ void mfma_qk(f32x16& acc, const f32x4v& k, const f32x4v& q) {
+    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(k), "a"(q));
+}
+__device__ __forceinline__ void scores_ready(f32x16 (&s)[2]) { asm volatile("s_nop 11" : "+v"(s[0]), "+v"(s[1])); }
+// single instructions the compiler would otherwise dress up (a canonicalising v_max in front of every fmaxf of an
+// MFMA output; adjacent adds packed into v_pk_add_f32, which is slower beside MFMAs)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float addf(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ void wait_vmcnt_mult4(int n) {   // n in {0, 4, ..., 28}
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;
+        case 4: wait_vmcnt<4>(); break;
+        case 8: wait_vmcnt<8>(); break;
+        case 12: wait_vmcnt<12>(); break;
+        case 16: wait_vmcnt<16>(); break;
+        case 20: wait_vmcnt<20>(); break;
+        case 24: wait_vmcnt<24>(); break;
+        case 28: wait_vmcnt<28>(); break;
+        default: wait_vmcnt<0>(); break;   // anything else: wait for everything (always safe)
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void attn_pipe_kernel(AttnArgs a) {
+    constexpr int PPW = 4;   // pieces of a 64-key tile per wave (16 x 1 KiB over 4 waves)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.y;
+    const int Lb = a.seq_len ? __builtin_amdgcn_readfirstlane(a.seq_len[b]) : a.L;
+    const int nt = a.seq_len ? Lb >> 6 : a.Lp >> 6;   // 1 .. 8
+    const size_t row0 = a.seq_off ? (size_t)__builtin_amdgcn_readfirstlane(a.seq_off[b]) : (size_t)b * a.L;
+    const char* sK = smem;
+    const char* sV = smem + nt * 8192;
+    const float* sBias = reinterpret_cast<const float*>(smem + 2 * nt * 8192);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    const int head = blockIdx.x;
+    const int ld = 3 * a.H;
+    const bf16_t* base = (const bf16_t*)a.QKV + row0 * ld + head * 64;
+    const bool active = wave * 32 < Lb;   // wave-uniform: does block 0 of this wave hold a query?
+
+    const u32 lds0 = (u32)(uintptr_t)(OTTER_AS3 char*)smem;
+    for (int i = wave; i < nt; i += 4)
+        dma4s(a.kbias + (size_t)b * a.Lp + i * 64, (u32)lane * 4u, lds0 + 2 * nt * 8192 + i * 256);
+    // query rows: loads hidden from hipcc (it would drain the DMA queue for them); rows past the sequence are clamped
+    f32x4v qf[4][4];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+        const int qrow = min((4 * qb + wave) * 32 + l31, Lb - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16_t* p = base + (size_t)qrow * ld + (2 * j + h) * 8;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(qf[qb][j]) : "v"(p) : "memory");
+        }
+    }
+    {
+        // piece p of a tile: p < 8 -> K rows 8p .. 8p+7 (chunks swizzled by (row >> 1) & 7), else V rows (linear)
+        u32 voff[PPW], dst[PPW];
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave * PPW + i, isv = p >> 3, r = 8 * (p & 7) + (lane >> 3);
+            const int c = isv ? (lane & 7) : ((lane & 7) ^ ((r >> 1) & 7));
+            voff[i] = ((u32)r * (u32)ld + (u32)(isv ? 2 * a.H : a.H) + (u32)(c * 8)) * 2u;
+            dst[i] = lds0 + (u32)(isv ? nt * 8192 : 0) + (u32)(p & 7) * 1024u;
+        }
+        for (int t = 0; t < nt; ++t) {
+            const char* tb = reinterpret_cast<const char*>(base) + (size_t)t * 64 * ld * 2;
+#if defined(ATTN_ABL) && ATTN_ABL == 2   // ablation: every tile re-reads tile 0's bytes (cache hits)
+            tb = reinterpret_cast<const char*>(base);
+#endif
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) dma16s(tb, voff[i], dst[i] + t * 8192);
+        }
+    }
+    // the query rows are older than the 4 nt pieces just issued: wait for exactly them
+    static_assert(PPW == 4, "wait_q_landed counts 4 pieces per tile");
+    wait_q_landed(qf, nt);
+
+    f32x16 o[4][2];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][d][r] = 0.0f;
+    float lsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // this lane's half of a row sum
+    // per-lane LDS byte offsets inside a tile (everything else is an immediate)
+    const int lswz = (l31 >> 1) & 7;
+    u32 kaddr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kaddr[j] = (u32)(l31 * 128 + (((2 * j + h) ^ lswz) << 4));
+    const int i16 = lane & 15;
+    const u32 vaddr = (u32)((4 * h + (i16 >> 2)) * 128 + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2);
+    const u32 baddr = (u32)(16 * h);
+
+    typedef int i32x2v __attribute__((ext_vector_type(2)));
+    typedef int i32x4v __attribute__((ext_vector_type(4)));
+    struct VFrag { i32x2v lo, hi; };   // keys kbase .. +3 and kbase + 8 .. +11 of 16 head dimensions, transposed
+
+    // --- pieces of a stage -------------------------------------------------------------------------------
+    auto ld_k = [&](const char* kt, int i) {   // fragment of score product i: keys 32 (i >> 2) .. +31, k-step i & 3
+        return *reinterpret_cast<const f32x4v*>(kt + (i >> 2) * 4096 + kaddr[i & 3]);
+    };
+    auto ld_bias = [&](const char* bt, int sub, f32x16& acc) {   // accumulator rows = keys 32 sub + 8 g + 4 h + (0 .. 3)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4v bb = *reinterpret_cast<const f32x4v*>(bt + baddr + sub * 128 + g * 32);
+            acc[4 * g + 0] = bb.x;
+            acc[4 * g + 1] = bb.y;
+            acc[4 * g + 2] = bb.z;
+            acc[4 * g + 3] = bb.w;
+        }
+    };
+    auto ld_v = [&](const char* vt, int i) {   // operand of context product i: sub = i >> 2, s2 = (i >> 1) & 1, d = i & 1
+        const char* p0 = vt + vaddr + ((i >> 2) * 32 + ((i >> 1) & 1) * 16) * 128 + (i & 1) * 64;
+        VFrag f;
+        f.lo = __builtin_bit_cast(i32x2v, __builtin_amdgcn_ds_read_tr16_b64_v4i16((OTTER_AS3 s16x4*)p0));
+        f.hi = __builtin_bit_cast(i32x2v, __builtin_amdgcn_ds_read_tr16_b64_v4i16((OTTER_AS3 s16x4*)(p0 + 8 * 128)));
+        return f;
+    };
+    auto mfma_pv = [&](f32x16& acc, const VFrag& f, const bf16x8& pb) {
+        const i32x4v av = {f.lo.x, f.lo.y, f.hi.x, f.hi.y};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), pb, acc, 0, 0, 0);
+    };
+    // slice k (0 .. 15) of the exponentials of a unit: two scores -> two probabilities, partial sums, one packed pair
+    auto exp_slice = [&](int k, const f32x16 (&sc)[2], float (&ps)[4], bf16x8 (&pc)[4]) {
+        const int sub = k >> 3, r0 = 2 * (k & 7);
+#if defined(ATTN_ABL) && ATTN_ABL == 4   // ablation: no exponentials, no sums
+        const float e0 = sc[sub][r0], e1 = sc[sub][r0 + 1];
+        if (k == 0) ps[0] = 1.0f;
+#else
+        const float e0 = __builtin_amdgcn_exp2f(sc[sub][r0]);
+        const float e1 = __builtin_amdgcn_exp2f(sc[sub][r0 + 1]);
+        ps[(2 * k) & 3] = addf(ps[(2 * k) & 3], e0);
+        ps[(2 * k + 1) & 3] = addf(ps[(2 * k + 1) & 3], e1);
+#endif
+        pc[sub * 2 + (r0 >> 3)][r0 & 7] = (__bf16)e0;
+        pc[sub * 2 + (r0 >> 3)][(r0 & 7) + 1] = (__bf16)e1;
+    };
+    // One stage.  Scores of unit u + 1 -> sn (tile t_qk, queries qn); context products of unit u - 1 (tile t_pv,
+    // probabilities pprev) -> oprev; exponentials of unit u (scores sc) -> pc, ls.  MFMA slot k: even = score
+    // product k / 2, odd = context product k / 2; the LDS reads of a slot are issued ATTN_PF slots ahead.  The scores
+    // read here were written by the asm MFMAs of the previous stage: its chain of keys 0 .. 31 ended in slot 6
+    // there, and the chain of keys 32 .. 63 (slot 14) is first read in slot 6 here -- far beyond the 12 wait
+    // states an MFMA result needs before the vector ALU may read it.
+    auto stage = [&](int t_qk, const f32x4v (&qn)[4], f32x16 (&sn)[2], int t_pv, const bf16x8 (&pprev)[4],
+                     f32x16 (&oprev)[2], const f32x16 (&sc)[2], float& ls, bf16x8 (&pc)[4]) {
+        const char* kt = sK + t_qk * 8192;
+        const char* vt = sV + t_pv * 8192;
+        const char* bt = reinterpret_cast<const char*>(sBias) + t_qk * 256;
+        f32x4v kf[8];
+        VFrag vf[8];
+        float ps[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#ifndef ATTN_PF
+#define ATTN_PF 6       // LDS reads are issued this many slots ahead of the MFMA that consumes them
+#endif
+#ifndef ATTN_PRE
+#define ATTN_PRE 4      // exponential slices done before the first MFMA (while its operands are on their way)
+#endif
+        constexpr int PF = ATTN_PF, PRE = ATTN_PRE;
+        auto ld_slot = [&](int k) {
+            if ((k & 1) == 0) kf[k >> 1] = ld_k(kt, k >> 1);
+            else vf[k >> 1] = ld_v(vt, k >> 1);
+            if (k == 8 - PF || (PF > 8 && k == 0)) ld_bias(bt, 1, sn[1]);   // the second chain starts in slot 8
+        };
+        ld_bias(bt, 0, sn[0]);
+#pragma unroll
+        for (int k = 0; k < PF; ++k) ld_slot(k);
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) exp_slice(k, sc, ps, pc);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k + PF < 16) ld_slot(k + PF);
+#if defined(ATTN_ABL) && ATTN_ABL == 5   // ablation: no MFMAs in the loop (operands still read)
+            if ((k & 1) == 0) asm volatile("" : "+v"(sn[k >> 3]) : "v"(kf[k >> 1]));
+            else asm volatile("" :: "v"(vf[k >> 1].lo), "v"(vf[k >> 1].hi), "v"(pprev[k >> 2]));
+#else
+            if ((k & 1) == 0) mfma_qk(sn[k >> 3], kf[k >> 1], qn[(k >> 1) & 3]);
+            else mfma_pv(oprev[(k >> 1) & 1], vf[k >> 1], pprev[k >> 2]);
+#endif
+            if (k + PRE < 16) exp_slice(k + PRE, sc, ps, pc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ls += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    };
+    // plain (unpipelined) pieces for the prologue, the drain and the safe path
+    auto qk = [&](int t, const f32x4v (&q)[4], f32x16 (&s)[2]) {
+        const char* kt = sK + t * 8192;
+        const char* bt = reinterpret_cast<const char*>(sBias) + t * 256;
+        ld_bias(bt, 0, s[0]);
+        ld_bias(bt, 1, s[1]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mfma_qk(s[i >> 2], ld_k(kt, i), q[i & 3]);
+        scores_ready(s);
+    };
+    auto pv = [&](int t, const bf16x8 (&p)[4], f32x16 (&oc)[2]) {
+        const char* vt = sV + t * 8192;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mfma_pv(oc[i & 1], ld_v(vt, i), p[i >> 1]);
+    };
+    auto tile_landed = [&](int t) {
+        wait_vmcnt_mult4(PPW * (nt - 1 - t));
+        asm volatile("s_barrier" ::: "memory");
+    };
+    // normalise and store one block: lanes l and l + 32 hold one query; after the swap a lane holds 8 consecutive
+    // head dimensions (16 B): half 0 -> [8 rq, 8 rq + 8), half 1 -> the next 8.  l: the full row sum.
+    auto store_block = [&](int qb, const f32x16 (&oc)[2], float l) {
+        int l31e = l31;
+        asm volatile("" : "+v"(l31e));   // (addresses derived here, not carried through the loops)
+        const int q = (4 * qb + wave) * 32 + l31e;
+        const float inv = 1.0f / l;
+        bf16_t* dst = (bf16_t*)a.CTX + (row0 + min(q, Lb - 1)) * a.H + head * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int rq = 0; rq < 4; rq += 2) {
+                bf16x8 ov;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u32x2v sw = __builtin_amdgcn_permlane32_swap(
+                        __float_as_uint(oc[d][4 * rq + i] * inv), __float_as_uint(oc[d][4 * rq + 4 + i] * inv), false, false);
+                    ov[i] = (__bf16)__uint_as_float(sw[0]);
+                    ov[4 + i] = (__bf16)__uint_as_float(sw[1]);
+                }
+                if (q < Lb) *reinterpret_cast<float4*>(dst + d * 32 + 8 * (rq + h)) = __builtin_bit_cast(float4, ov);
+            }
+    };
+
+    f32x16 s[2][2];      // scores of the unit being exponentiated / being produced, by block parity
+    bf16x8 p[2][4];      // P operand of the unit before / of this unit, by block parity
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[1][i][j] = (__bf16)0.0f;   // "unit -1": adds nothing
+
+    tile_landed(0);
+    if (!active) {   // a wave without queries only takes part in the barriers
+        for (int t = 1; t < nt; ++t) tile_landed(t);
+        return;
+    }
+#if defined(ATTN_ABL) && ATTN_ABL == 1   // ablation: fill only
+    for (int t = 1; t < nt; ++t) tile_landed(t);
+    return;
+#endif
+    qk(0, qf[0], s[0]);
+    for (int t = 0; t < nt; ++t) {
+        const bool more = t + 1 < nt;
+        if (more) tile_landed(t + 1);
+#if defined(ATTN_ABL) && ATTN_ABL == 3   // ablation: prologue, barriers, ONE tile and the store
+        if (t > 0) continue;
+#endif
+        const int tn = more ? t + 1 : t;    // (no next tile: the last one again, result unused)
+        const int tp = t > 0 ? t - 1 : 0;   // (no previous tile: P is zero)
+        stage(t, qf[1], s[1], tp, p[1], o[3], s[0], lsum[0], p[0]);   // unit (t, 0)
+        stage(t, qf[2], s[0], t, p[0], o[0], s[1], lsum[1], p[1]);    // unit (t, 1)
+        stage(t, qf[3], s[1], t, p[1], o[1], s[0], lsum[2], p[0]);    // unit (t, 2)
+        stage(tn, qf[0], s[0], t, p[0], o[2], s[1], lsum[3], p[1]);   // unit (t, 3)
+    }
+    pv(nt - 1, p[1], o[3]);
+
+    // accept a block iff all its row sums are of sane magnitude; else recompute it the safe way
+    bool good[4];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+        float l = lsum[qb];
+        const u32x2v sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
+        l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        lsum[qb] = l;
+        good[qb] = __ballot(!(l > 1e-30f && l < 1e30f)) == 0ull;
+    }
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb)
+        if (good[qb]) store_block(qb, o[qb], lsum[qb]);
+    if (good[0] && good[1] && good[2] && good[3]) return;
+
+    // safe path: online softmax with a running maximum, one block at a time (rows with every key masked come out as
+    // the mean over those keys, as in attn_kernel)
+    auto safe_block = [&](int qb, const f32x4v(&qv)[4]) {
+        f32x16 os[2], ss[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) os[d][r] = 0.0f;
+        float mrun = -INFINITY, lrun = 0.0f;
+        for (int t = 0; t < nt; ++t) {
+            qk(t, qv, ss);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, ss[sub][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrun, mx);
+            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+            float psum = 0.0f;
+            bf16x8 pb[4];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(ss[sub][r] - mnew);
+                    psum += e;
+                    pb[sub * 2 + (r >> 3)][r & 7] = (__bf16)e;
+                }
+            lrun = lrun * alpha + psum;
+            mrun = mnew;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) os[d][r] *= alpha;
+            pv(t, pb, os);
+        }
+        lrun += __shfl_xor(lrun, 32);
+        store_block(qb, os, lrun);
+    };
+    if (!good[0]) safe_block(0, qf[0]);
+    if (!good[1]) safe_block(1, qf[1]);
+    if (!good[2]) safe_block(2, qf[2]);
+    if (!good[3]) safe_block(3, qf[3]);
+}
+
 int launch_attn_bf16(const AttnArgs& a, hipStream_t st) {
     const int nt = a.Lp >> 6;
     const int lds = 2 * nt * 8192 + nt * 256;
+    static const bool old_kernel = [] {
+        const char* v = getenv("OTTER_ATTN_OLD");   // A/B switch: the round-2 kernel (expects unscaled queries: only
+        return v && v[0] == '1';                    // meaningful for timing)
+    }();
+    if (!old_kernel) {
+        OTTER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pipe_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(attn_pipe_kernel, dim3(a.heads, a.B), dim3(256), lds, st, a);
+        OTTER_HIP_TRY(hipGetLastError());
+        return OTTER_OK;
+    }
     // 8 waves x 64 queries.  (A 16-wave x 32-query form exists as attn_full_kernel<1>; it needs 128 registers per
     // lane, spills, and is not launched: a kernel whose hidden asynchronous loads land in registers must not spill.)
     OTTER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<2>),
@@ -916,6 +1309,11 @@ __global__ void to_f32_kernel(const T* src, float* dst, long long n) {
         dst[i] = to_f<T>(src[i]);
 }
 
+__global__ void scale_copy_kernel(const float* src, float* dst, long long n, float f) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = src[i] * f;
+}
+
 template <typename T>
 __global__ void from_f32_kernel(const float* src, T* dst, long long n) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -960,6 +1358,10 @@ struct otter_encoder {
     otter::DevBuf part, stat1, stat2;   // LayerNorm statistics of the fused bf16 path
     otter::DevBuf seq;                  // packed batches: seq_len[B], seq_off[B], info[2]
     bool ln_fused = false;
+    // attn_kernel's score scale.  fp32: 1/sqrt(64).  bf16: the query projection is stored pre-multiplied by
+    // (1/sqrt(64)) log2(e) (attn_pipe_kernel exponentiates its scores in base 2 as they come out of the MFMA chain),
+    // so the natural-exponent fallback kernel multiplies by ln 2.
+    float attn_scale = 0.125f;
     long long ws_rows = 0;
 };
 
@@ -1024,18 +1426,40 @@ int finalize_t(otter_encoder* e) {
     const size_t H = c.hidden_size, I = c.intermediate_size;
     hipStream_t st = nullptr;
     e->layers.resize(c.num_hidden_layers);
+    // bf16: W_q and b_q times (1/sqrt(d_head)) log2(e), in fp32, before anything is derived from them
+    const float dh_scale = 1.0f / sqrtf((float)(H / c.num_attention_heads));
+    float *wq_s = nullptr, *bq_s = nullptr;
+    e->attn_scale = dh_scale;
+    if (sizeof(T) == 2) {
+        OTTER_HIP_TRY(hipMalloc((void**)&wq_s, H * H * sizeof(float)));
+        OTTER_HIP_TRY(hipMalloc((void**)&bq_s, H * sizeof(float)));
+        e->attn_scale = 0.69314718055994531f;
+    }
+    struct TmpFree {
+        float *a, *b;
+        ~TmpFree() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); }
+    } tmp_free{wq_s, bq_s};
     for (int li = 0; li < c.num_hidden_layers; ++li) {
         const std::string p = "encoder.layer." + std::to_string(li) + ".";
         LayerW& L = e->layers[li];
         int rc;
+        const float* wsrc[3] = {e->w[p + "attention.self.query.weight"].d, e->w[p + "attention.self.key.weight"].d,
+                                e->w[p + "attention.self.value.weight"].d};
+        const float* bsrc[3] = {e->w[p + "attention.self.query.bias"].d, e->w[p + "attention.self.key.bias"].d,
+                                e->w[p + "attention.self.value.bias"].d};
+        if (sizeof(T) == 2) {
+            const float f = dh_scale * 1.4426950408889634f;
+            hipLaunchKernelGGL(scale_copy_kernel, dim3(1024), dim3(256), 0, st, wsrc[0], wq_s, (long long)(H * H), f);
+            hipLaunchKernelGGL(scale_copy_kernel, dim3(4), dim3(256), 0, st, bsrc[0], bq_s, (long long)H, f);
+            OTTER_HIP_TRY(hipGetLastError());
+            wsrc[0] = wq_s;
+            bsrc[0] = bq_s;
+        }
         if ((rc = dev_alloc(e, &L.wqkv, 3 * H * H * sizeof(T)))) return rc;
         if ((rc = dev_alloc(e, (void**)&L.bqkv, 3 * H * sizeof(float)))) return rc;
-        const char* names[3] = {"attention.self.query", "attention.self.key", "attention.self.value"};
         for (int t = 0; t < 3; ++t) {
-            if ((rc = convert_to<T>(e->w[p + names[t] + ".weight"].d, (char*)L.wqkv + t * H * H * sizeof(T), H * H, st)))
-                return rc;
-            OTTER_HIP_TRY(hipMemcpyAsync(L.bqkv + t * H, e->w[p + names[t] + ".bias"].d, H * sizeof(float),
-                                         hipMemcpyDeviceToDevice, st));
+            if ((rc = convert_to<T>(wsrc[t], (char*)L.wqkv + t * H * H * sizeof(T), H * H, st))) return rc;
+            OTTER_HIP_TRY(hipMemcpyAsync(L.bqkv + t * H, bsrc[t], H * sizeof(float), hipMemcpyDeviceToDevice, st));
         }
         struct { const char* n; void** dst; size_t cnt; } mats[3] = {
             {"attention.output.dense.weight", &L.wo, H * H},
@@ -1071,7 +1495,7 @@ int finalize_t(otter_encoder* e) {
                 if ((rc = dev_alloc(e, (void**)&L.sqkv, 3 * H * sizeof(float)))) return rc;
                 if ((rc = dev_alloc(e, (void**)&L.cqkv, 3 * H * sizeof(float)))) return rc;
                 for (int t = 0; t < 3; ++t)
-                    if ((rc = launch_fold_ln(e->w[p + names[t] + ".weight"].d, P.ln2g, P.ln2b, L.bqkv + t * H,
+                    if ((rc = launch_fold_ln(wsrc[t], P.ln2g, P.ln2b, L.bqkv + t * H,
                                              (char*)L.wqkv_f + t * H * H * sizeof(T), L.sqkv + t * H, L.cqkv + t * H,
                                              (int)H, (int)H, st)))
                         return rc;
@@ -1155,7 +1579,7 @@ int run_layers_nv(otter_encoder* e, const int64_t* ids, const int64_t* mask, con
         AttnArgs a;
         a.QKV = e->QKV.p; a.CTX = e->CTX.p; a.kbias = (const float*)e->kbias.p;
         a.B = B; a.L = L; a.Lp = Lp; a.H = H; a.heads = c.num_attention_heads;
-        a.scale = 1.0f / sqrtf((float)(H / c.num_attention_heads));
+        a.scale = e->attn_scale;
         if (sizeof(T) == 2 && L <= 512) {
             if ((rc = launch_attn_bf16(a, st))) return rc;
         } else {
@@ -1238,7 +1662,7 @@ int run_layers_fused(otter_encoder* e, const int64_t* ids, const int64_t* mask, 
         AttnArgs a;
         a.QKV = e->QKV.p; a.CTX = e->CTX.p; a.kbias = (const float*)e->kbias.p;
         a.B = B; a.L = L; a.Lp = Lp; a.H = H; a.heads = c.num_attention_heads;
-        a.scale = 1.0f / sqrtf((float)(H / c.num_attention_heads));
+        a.scale = e->attn_scale;
         a.seq_off = seq_off; a.seq_len = seq_len;
         if (L <= 512) {
             if ((rc = launch_attn_bf16(a, st))) return rc;
