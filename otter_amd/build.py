@@ -22,9 +22,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-Wa
 # Kernels that load into REGISTERS from inline asm and wait for them by hand (counted vmcnt): the register allocator
 # does not know the destination is still in flight, so a spill there is not just slow -- it may reuse a register an
 # asynchronous load is still going to write (seen once as a GPU memory fault).  The build fails if one needs scratch.
-NO_SPILL = ("attn_full_kernel", "attn_pipe_kernel")
+NO_SPILL = ("attn_full_kernel",)
 # Hot kernels whose loads are LDS-DMA (no register destination): a spill is a performance bug, reported, not fatal.
-WARN_SPILL = ("scan_kernel", "scan16_kernel", "stream_kernel", "stream16_kernel", "stream32_kernel", "gemm_pp_kernel",
+WARN_SPILL = ("attn_pipe_kernel", "scan_kernel", "scan16_kernel", "stream_kernel", "stream16_kernel", "stream32_kernel", "gemm_pp_kernel",
               "merge_kernel")
 
 

@@ -185,6 +185,10 @@ struct AttnArgs {
     // [seq_off[b], seq_off[b] + seq_len[b]) of QKV / CTX, seq_len a multiple of 64 (<= Lp)
     const int* seq_off = nullptr;
     const int* seq_len = nullptr;
+    // attn_pipe_kernel -> attn_kernel: one byte per 32-query block, [B][heads][16], non-zero = "recompute this block"
+    // (attn_kernel with flags set works on the 128-query groups that hold a flagged block and exits on the others)
+    unsigned char* flags = nullptr;
+    int ncu = 256;
 };
 
 template <typename T>
@@ -202,13 +206,18 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.z, head = blockIdx.y;
+    // as the repair pass behind attn_pipe_kernel: only the 128-query groups that hold a flagged block
+    if (a.flags && reinterpret_cast<const unsigned*>(a.flags)[((size_t)b * a.heads + head) * 4 + blockIdx.x] == 0u) return;
+    const int L = a.seq_len ? a.seq_len[b] : a.L;                       // rows of this sequence (packed: a multiple of 64)
+    const size_t row0 = a.seq_off ? (size_t)a.seq_off[b] : (size_t)b * a.L;
+    if ((int)blockIdx.x * 128 >= L) return;
     const int q0 = blockIdx.x * 128 + wave * 32;
     const int ld = 3 * a.H;
-    const T* base = (const T*)a.QKV + (size_t)b * a.L * ld + head * DH;
+    const T* base = (const T*)a.QKV + row0 * ld + head * DH;
     auto swz = [](int r) { return CH == 16 ? (r & 15) : ((r >> 1) & 7); };
 
     // this lane's query row (clamped: rows past L are computed and dropped)
-    const int qrow = min(q0 + l31, a.L - 1);
+    const int qrow = min(q0 + l31, L - 1);
     float4 qf[NQ];
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) o[d][r] = 0.0f;
     float mrun = -INFINITY, lrun = 0.0f;
 
-    for (int kb0 = 0; kb0 < a.L; kb0 += KB) {
+    for (int kb0 = 0; kb0 < L; kb0 += KB) {
         __syncthreads();
         // stage K (swizzled chunks) and V (row-major) of keys kb0 .. kb0+63
         for (int c = tid; c < KB * CH; c += 256) {
@@ -322,9 +331,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 
     // normalise and store: lane = query, registers = head dimension
     const int q = q0 + l31;
-    if (q < a.L) {
+    if (q < L) {
         const float inv = 1.0f / lrun;
-        T* dst = (T*)a.CTX + ((size_t)b * a.L + q) * a.H + head * DH;
+        T* dst = (T*)a.CTX + (row0 + q) * a.H + head * DH;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -656,29 +665,6 @@ __global__ __launch_bounds__(1024 / QB, QB == 2 ? 2 : 4) void attn_full_kernel(A
 //     lies in (1e-30, 1e30) (then no exponential overflowed, no context sum can have, and nothing underflowed);
 //     otherwise -- scores beyond +-100, or rows with every key masked -- the wave recomputes that block with a
 //     plain online-softmax loop (attn_block_safe below; slow, exact, never taken on sane inputs).
-// Wait until all but the youngest 4 * nt vector-memory operations of this wave are done (nt = 1 .. 8) and only then
-// let the compiler see the query registers as written.  ONE statement on purpose: the wait and the "written now"
-// fence cannot be separated, and there is one set of tied operands (a switch over eight statements made hipcc copy
-// the registers in front of the waits, i.e. read them before the loads had landed).  The query fragments live in
-// accumulator registers: only MFMAs read them.
-__device__ __forceinline__ void wait_q_landed(f32x4v (&q)[4][4], int nt) {
-    asm volatile(
-        "s_waitcnt vmcnt(32)\n\t"
-        "s_cmp_ge_u32 %16, 8\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(28)\n\t"
-        "s_cmp_ge_u32 %16, 7\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(24)\n\t"
-        "s_cmp_ge_u32 %16, 6\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(20)\n\t"
-        "s_cmp_ge_u32 %16, 5\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(16)\n\t"
-        "s_cmp_ge_u32 %16, 4\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(12)\n\t"
-        "s_cmp_ge_u32 %16, 3\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(8)\n\t"
-        "s_cmp_ge_u32 %16, 2\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(4)\n"
-        "1:"
-        : "+a"(q[0][0]), "+a"(q[0][1]), "+a"(q[0][2]), "+a"(q[0][3]), "+a"(q[1][0]), "+a"(q[1][1]), "+a"(q[1][2]),
-          "+a"(q[1][3]), "+a"(q[2][0]), "+a"(q[2][1]), "+a"(q[2][2]), "+a"(q[2][3]), "+a"(q[3][0]), "+a"(q[3][1]),
-          "+a"(q[3][2]), "+a"(q[3][3])
-        : "s"(nt)
-        : "memory", "scc");
-}
-
 // The score products are written as asm: hipcc selects ONE register class for the accumulators of every MFMA builtin
 // of a kernel, and in a 512-register kernel that is the accumulator file -- right for the context accumulators (only
 // MFMAs touch them), wrong for the scores, which the vector ALU reads: every score would be copied out with
@@ -688,107 +674,107 @@ __device__ __forceinline__ void wait_q_landed(f32x4v (&q)[4][4], int nt) {
 // by the vector ALU for 12 wait states (8-pass MFMA); in the pipelined loop the first reader is a whole stage away
 // (order pinned by sched_barrier), elsewhere scores_ready() stands between.
 __device__ __forceinline__ void mfma_qk(f32x16& acc, const f32x4v& k, const f32x4v& q) {
-    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(k), "a"(q));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k), __builtin_bit_cast(bf16x8, q), acc, 0, 0, 0);
 }
-__device__ __forceinline__ void scores_ready(f32x16 (&s)[2]) { asm volatile("s_nop 11" : "+v"(s[0]), "+v"(s[1])); }
-// single instructions the compiler would otherwise dress up (a canonicalising v_max in front of every fmaxf of an
-// MFMA output; adjacent adds packed into v_pk_add_f32, which is slower beside MFMAs)
-__device__ __forceinline__ float max3f(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+__device__ __forceinline__ void mfma_qk0(f32x16& acc, const f32x4v& k, const f32x4v& q) {   // C = 0: starts a chain
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k), __builtin_bit_cast(bf16x8, q), z, 0, 0, 0);
 }
-__device__ __forceinline__ float addf(float a, float b) {
-    float r;
-    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
+__device__ __forceinline__ void scores_ready(f32x16 (&)[2]) {}
+struct AttnItem {
+    int b, head, Lb, nt;
+    size_t row0;
+    const bf16_t* base;   // q | k | v of the head, row 0 of the sequence
+};
 
-__device__ __forceinline__ void wait_vmcnt_mult4(int n) {   // n in {0, 4, ..., 28}
-    switch (n) {
-        case 0: wait_vmcnt<0>(); break;
-        case 4: wait_vmcnt<4>(); break;
-        case 8: wait_vmcnt<8>(); break;
-        case 12: wait_vmcnt<12>(); break;
-        case 16: wait_vmcnt<16>(); break;
-        case 20: wait_vmcnt<20>(); break;
-        case 24: wait_vmcnt<24>(); break;
-        case 28: wait_vmcnt<28>(); break;
-        default: wait_vmcnt<0>(); break;   // anything else: wait for everything (always safe)
-    }
-}
-
-__global__ __launch_bounds__(256, 1) void attn_pipe_kernel(AttnArgs a) {
-    constexpr int PPW = 4;   // pieces of a 64-key tile per wave (16 x 1 KiB over 4 waves)
+__global__ __launch_bounds__(512, 2) void attn_pipe_kernel(AttnArgs a) {
+    constexpr int LDS_V = 65536, LDS_B = 131072;   // K tiles | V tiles | key bias (8 tiles each: L <= 512)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int b = blockIdx.y;
-    const int Lb = a.seq_len ? __builtin_amdgcn_readfirstlane(a.seq_len[b]) : a.L;
-    const int nt = a.seq_len ? Lb >> 6 : a.Lp >> 6;   // 1 .. 8
-    const size_t row0 = a.seq_off ? (size_t)__builtin_amdgcn_readfirstlane(a.seq_off[b]) : (size_t)b * a.L;
     const char* sK = smem;
-    const char* sV = smem + nt * 8192;
-    const float* sBias = reinterpret_cast<const float*>(smem + 2 * nt * 8192);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5, l31 = lane & 31;
-    const int head = blockIdx.x;
+    const char* sV = smem + LDS_V;
+    const char* sBias = smem + LDS_B;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ld = 3 * a.H;
-    const bf16_t* base = (const bf16_t*)a.QKV + row0 * ld + head * 64;
-    const bool active = wave * 32 < Lb;   // wave-uniform: does block 0 of this wave hold a query?
-
+    const int n_items = a.B * a.heads;
     const u32 lds0 = (u32)(uintptr_t)(OTTER_AS3 char*)smem;
-    for (int i = wave; i < nt; i += 4)
-        dma4s(a.kbias + (size_t)b * a.Lp + i * 64, (u32)lane * 4u, lds0 + 2 * nt * 8192 + i * 256);
-    // query rows: loads hidden from hipcc (it would drain the DMA queue for them); rows past the sequence are clamped
-    f32x4v qf[4][4];
+    // Per-lane constants are derived from the lane id where they are used (v_mbcnt: two instructions), per item, not
+    // once at kernel entry: kept alive across an item's prologue and store they were spilled, and the s_waitcnt vmcnt(0)
+    // of a reload inside the tile loop drains the refill DMA the loop is there to hide.
+    // (asm volatile: as a builtin the value is loop-invariant, gets hoisted to kernel entry and spilled all the same)
+    auto lane_id = [&]() {
+        int x;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+        return x;
+    };
+
+    // --- the fill: LDS-DMA pieces of a 64-key tile (16 x 1 KiB, 2 per wave), key bias, query rows ---------------
+    // piece p of a tile: p < 8 -> K rows 8p .. 8p+7 (chunks swizzled by (row >> 1) & 7), else V rows (linear)
+    u32 dst[2];
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb) {
-        const int qrow = min((4 * qb + wave) * 32 + l31, Lb - 1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bf16_t* p = base + (size_t)qrow * ld + (2 * j + h) * 8;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(qf[qb][j]) : "v"(p) : "memory");
-        }
+    for (int i = 0; i < 2; ++i) {
+        const int p = wave * 2 + i, isv = p >> 3;
+        dst[i] = lds0 + (u32)(isv ? LDS_V : 0) + (u32)(p & 7) * 1024u;
     }
-    {
-        // piece p of a tile: p < 8 -> K rows 8p .. 8p+7 (chunks swizzled by (row >> 1) & 7), else V rows (linear)
-        u32 voff[PPW], dst[PPW];
+    auto piece_offsets = [&](u32 (&voff)[2]) {
+        const int lane = lane_id();
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int p = wave * PPW + i, isv = p >> 3, r = 8 * (p & 7) + (lane >> 3);
+        for (int i = 0; i < 2; ++i) {
+            const int p = wave * 2 + i, isv = p >> 3, r = 8 * (p & 7) + (lane >> 3);
             const int c = isv ? (lane & 7) : ((lane & 7) ^ ((r >> 1) & 7));
             voff[i] = ((u32)r * (u32)ld + (u32)(isv ? 2 * a.H : a.H) + (u32)(c * 8)) * 2u;
-            dst[i] = lds0 + (u32)(isv ? nt * 8192 : 0) + (u32)(p & 7) * 1024u;
         }
-        for (int t = 0; t < nt; ++t) {
-            const char* tb = reinterpret_cast<const char*>(base) + (size_t)t * 64 * ld * 2;
-#if defined(ATTN_ABL) && ATTN_ABL == 2   // ablation: every tile re-reads tile 0's bytes (cache hits)
-            tb = reinterpret_cast<const char*>(base);
-#endif
+    };
+    auto geom = [&](int it) {
+        AttnItem g;
+        g.b = it / a.heads;
+        g.head = it - g.b * a.heads;
+        g.Lb = a.seq_len ? __builtin_amdgcn_readfirstlane(a.seq_len[g.b]) : a.L;
+        g.nt = a.seq_len ? g.Lb >> 6 : a.Lp >> 6;   // 1 .. 8
+        g.row0 = a.seq_off ? (size_t)__builtin_amdgcn_readfirstlane(a.seq_off[g.b]) : (size_t)g.b * a.L;
+        g.base = (const bf16_t*)a.QKV + g.row0 * ld + g.head * 64;
+        return g;
+    };
+    auto issue_tile = [&](const AttnItem& g, int t, const u32 (&voff)[2]) {
+        const char* tb = reinterpret_cast<const char*>(g.base) + (size_t)t * 64 * ld * 2;
 #pragma unroll
-            for (int i = 0; i < PPW; ++i) dma16s(tb, voff[i], dst[i] + t * 8192);
+        for (int i = 0; i < 2; ++i) dma16s(tb, voff[i], dst[i] + t * 8192);
+    };
+    auto issue_bias = [&](const AttnItem& g) {
+        if (wave < g.nt) dma4s(a.kbias + (size_t)g.b * a.Lp + wave * 64, (u32)lane_id() * 4u, lds0 + LDS_B + wave * 256);
+    };
+    // query rows of this wave's blocks (wave, wave + 8); rows past the sequence are clamped (computed, never stored).
+    // Plain loads, which hipcc counts: its own s_waitcnt for them can only be stronger than needed (the LDS-DMA
+    // pieces issued around them are invisible to it and only add to the real count), never weaker -- unlike loads
+    // hidden in asm, no register is ever read before it has landed, whatever the register allocator does.
+    auto issue_q = [&](const AttnItem& g, f32x4v (&q)[2][4]) {
+        const int lane = lane_id(), h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int qrow = min((8 * i + wave) * 32 + l31, g.Lb - 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                q[i][j] = *reinterpret_cast<const f32x4v*>(g.base + (size_t)qrow * ld + (2 * j + h) * 8);
         }
-    }
-    // the query rows are older than the 4 nt pieces just issued: wait for exactly them
-    static_assert(PPW == 4, "wait_q_landed counts 4 pieces per tile");
-    wait_q_landed(qf, nt);
+    };
+    // everything this wave has issued is done, then for every wave
+    auto fill_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };
 
-    f32x16 o[4][2];
-#pragma unroll
-    for (int qb = 0; qb < 4; ++qb)
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[qb][d][r] = 0.0f;
-    float lsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // this lane's half of a row sum
-    // per-lane LDS byte offsets inside a tile (everything else is an immediate)
-    const int lswz = (l31 >> 1) & 7;
-    u32 kaddr[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) kaddr[j] = (u32)(l31 * 128 + (((2 * j + h) ^ lswz) << 4));
-    const int i16 = lane & 15;
-    const u32 vaddr = (u32)((4 * h + (i16 >> 2)) * 128 + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2);
-    const u32 baddr = (u32)(16 * h);
+    // per-lane LDS byte offsets inside a tile (everything else is an immediate); set per item, see lane_id()
+    u32 kaddr0 = 0, vaddr = 0, baddr = 0;
+    float one = 1.0f;   // made opaque per item (exp_slice)
+    auto lds_offsets = [&]() {
+        const int lane = lane_id(), h = lane >> 5, l31 = lane & 31, i16 = lane & 15;
+        const int lswz = (l31 >> 1) & 7;
+        // K fragment of k-step j: chunk (2 j + h) ^ lswz of row l31 = kaddr0 ^ (j << 5)  (2 j + h = 2 j ^ h)
+        kaddr0 = (u32)(l31 * 128 + ((h ^ lswz) << 4));
+        vaddr = (u32)((4 * h + (i16 >> 2)) * 128 + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2);
+        baddr = (u32)(16 * h);
+        one = 1.0f;
+        asm volatile("" : "+v"(one));
+    };
 
     typedef int i32x2v __attribute__((ext_vector_type(2)));
     typedef int i32x4v __attribute__((ext_vector_type(4)));
@@ -796,7 +782,7 @@ __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(AttnArgs a) {
 
     // --- pieces of a stage -------------------------------------------------------------------------------
     auto ld_k = [&](const char* kt, int i) {   // fragment of score product i: keys 32 (i >> 2) .. +31, k-step i & 3
-        return *reinterpret_cast<const f32x4v*>(kt + (i >> 2) * 4096 + kaddr[i & 3]);
+        return *reinterpret_cast<const f32x4v*>(kt + (i >> 2) * 4096 + (kaddr0 ^ (u32)((i & 3) << 5)));
     };
     auto ld_bias = [&](const char* bt, int sub, f32x16& acc) {   // accumulator rows = keys 32 sub + 8 g + 4 h + (0 .. 3)
 #pragma unroll
@@ -820,47 +806,42 @@ __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(AttnArgs a) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), pb, acc, 0, 0, 0);
     };
     // slice k (0 .. 15) of the exponentials of a unit: two scores -> two probabilities, partial sums, one packed pair
-    auto exp_slice = [&](int k, const f32x16 (&sc)[2], float (&ps)[4], bf16x8 (&pc)[4]) {
+    auto exp_slice = [&](int k, const f32x16 (&sc)[2], float (&ps)[2], bf16x8 (&pc)[4]) {
         const int sub = k >> 3, r0 = 2 * (k & 7);
-#if defined(ATTN_ABL) && ATTN_ABL == 4   // ablation: no exponentials, no sums
-        const float e0 = sc[sub][r0], e1 = sc[sub][r0 + 1];
-        if (k == 0) ps[0] = 1.0f;
-#else
         const float e0 = __builtin_amdgcn_exp2f(sc[sub][r0]);
         const float e1 = __builtin_amdgcn_exp2f(sc[sub][r0 + 1]);
-        ps[(2 * k) & 3] = addf(ps[(2 * k) & 3], e0);
-        ps[(2 * k + 1) & 3] = addf(ps[(2 * k + 1) & 3], e1);
-#endif
+        // Two dependent chains in plain C++, one of adds and one of fmas by an opaque 1.0: two chains of adds get
+        // packed into v_pk_add_f32 (slower beside MFMAs), and an asm v_add right behind the v_exp whose result it reads
+        // is a hazard hipcc cannot pad (a transcendental's result needs a wait state before the next vector
+        // instruction reads it: seen as wrong row sums)
+        ps[0] += e0;
+        ps[1] = __builtin_fmaf(e1, one, ps[1]);
         pc[sub * 2 + (r0 >> 3)][r0 & 7] = (__bf16)e0;
         pc[sub * 2 + (r0 >> 3)][(r0 & 7) + 1] = (__bf16)e1;
     };
     // One stage.  Scores of unit u + 1 -> sn (tile t_qk, queries qn); context products of unit u - 1 (tile t_pv,
     // probabilities pprev) -> oprev; exponentials of unit u (scores sc) -> pc, ls.  MFMA slot k: even = score
-    // product k / 2, odd = context product k / 2; the LDS reads of a slot are issued ATTN_PF slots ahead.  The scores
-    // read here were written by the asm MFMAs of the previous stage: its chain of keys 0 .. 31 ended in slot 6
-    // there, and the chain of keys 32 .. 63 (slot 14) is first read in slot 6 here -- far beyond the 12 wait
+    // product k / 2, odd = context product k / 2; the LDS reads of a slot are issued PF slots ahead.  `mk`: tile
+    // t_qk holds a masked key -- then the score accumulators start from the key bias (read from LDS straight into
+    // them), else from the MFMA's constant 0.
+    // The scores read here were written by the asm MFMAs of the previous stage: its chain of keys 0 .. 31 ended in
+    // slot 6 there, and the chain of keys 32 .. 63 (slot 14) is first read in slot 4 here -- far beyond the 12 wait
     // states an MFMA result needs before the vector ALU may read it.
-    auto stage = [&](int t_qk, const f32x4v (&qn)[4], f32x16 (&sn)[2], int t_pv, const bf16x8 (&pprev)[4],
+    auto stage = [&](int t_qk, bool mk, const f32x4v (&qn)[4], f32x16 (&sn)[2], int t_pv, const bf16x8 (&pprev)[4],
                      f32x16 (&oprev)[2], const f32x16 (&sc)[2], float& ls, bf16x8 (&pc)[4]) {
         const char* kt = sK + t_qk * 8192;
         const char* vt = sV + t_pv * 8192;
-        const char* bt = reinterpret_cast<const char*>(sBias) + t_qk * 256;
+        const char* bt = sBias + t_qk * 256;
         f32x4v kf[8];
         VFrag vf[8];
-        float ps[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#ifndef ATTN_PF
-#define ATTN_PF 6       // LDS reads are issued this many slots ahead of the MFMA that consumes them
-#endif
-#ifndef ATTN_PRE
-#define ATTN_PRE 4      // exponential slices done before the first MFMA (while its operands are on their way)
-#endif
-        constexpr int PF = ATTN_PF, PRE = ATTN_PRE;
+        float ps[2] = {0.0f, 0.0f};
+        constexpr int PF = 2;    // LDS reads run this many slots ahead of the MFMA that consumes them
+        constexpr int PRE = 2;   // exponential slices done before the first MFMA (while its operands are on their way)
         auto ld_slot = [&](int k) {
             if ((k & 1) == 0) kf[k >> 1] = ld_k(kt, k >> 1);
             else vf[k >> 1] = ld_v(vt, k >> 1);
-            if (k == 8 - PF || (PF > 8 && k == 0)) ld_bias(bt, 1, sn[1]);   // the second chain starts in slot 8
         };
-        ld_bias(bt, 0, sn[0]);
+        if (mk) ld_bias(bt, 0, sn[0]);
 #pragma unroll
         for (int k = 0; k < PF; ++k) ld_slot(k);
 #pragma unroll
@@ -869,22 +850,24 @@ __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(AttnArgs a) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             if (k + PF < 16) ld_slot(k + PF);
-#if defined(ATTN_ABL) && ATTN_ABL == 5   // ablation: no MFMAs in the loop (operands still read)
-            if ((k & 1) == 0) asm volatile("" : "+v"(sn[k >> 3]) : "v"(kf[k >> 1]));
-            else asm volatile("" :: "v"(vf[k >> 1].lo), "v"(vf[k >> 1].hi), "v"(pprev[k >> 2]));
-#else
-            if ((k & 1) == 0) mfma_qk(sn[k >> 3], kf[k >> 1], qn[(k >> 1) & 3]);
-            else mfma_pv(oprev[(k >> 1) & 1], vf[k >> 1], pprev[k >> 2]);
-#endif
+            if (k == 8 - PF && mk) ld_bias(bt, 1, sn[1]);   // (the second chain starts in slot 8; its registers are the
+                                                            // ones the first half of `sc` dies in)
+            if ((k & 1) == 0) {
+                const int i = k >> 1;   // score product i: chain i >> 2, k-step i & 3
+                if ((i & 3) == 0 && !mk) mfma_qk0(sn[i >> 2], kf[i], qn[i & 3]);
+                else mfma_qk(sn[i >> 2], kf[i], qn[i & 3]);
+            } else {
+                mfma_pv(oprev[(k >> 1) & 1], vf[k >> 1], pprev[k >> 2]);
+            }
             if (k + PRE < 16) exp_slice(k + PRE, sc, ps, pc);
             __builtin_amdgcn_sched_barrier(0);
         }
-        ls += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        ls += ps[0] + ps[1];
     };
-    // plain (unpipelined) pieces for the prologue, the drain and the safe path
+    // plain (unpipelined) pieces for the first unit of an item and the drain
     auto qk = [&](int t, const f32x4v (&q)[4], f32x16 (&s)[2]) {
         const char* kt = sK + t * 8192;
-        const char* bt = reinterpret_cast<const char*>(sBias) + t * 256;
+        const char* bt = sBias + t * 256;
         ld_bias(bt, 0, s[0]);
         ld_bias(bt, 1, s[1]);
 #pragma unroll
@@ -896,18 +879,13 @@ __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) mfma_pv(oc[i & 1], ld_v(vt, i), p[i >> 1]);
     };
-    auto tile_landed = [&](int t) {
-        wait_vmcnt_mult4(PPW * (nt - 1 - t));
-        asm volatile("s_barrier" ::: "memory");
-    };
     // normalise and store one block: lanes l and l + 32 hold one query; after the swap a lane holds 8 consecutive
     // head dimensions (16 B): half 0 -> [8 rq, 8 rq + 8), half 1 -> the next 8.  l: the full row sum.
-    auto store_block = [&](int qb, const f32x16 (&oc)[2], float l) {
-        int l31e = l31;
-        asm volatile("" : "+v"(l31e));   // (addresses derived here, not carried through the loops)
-        const int q = (4 * qb + wave) * 32 + l31e;
+    auto store_block = [&](const AttnItem& g, int blk, const f32x16 (&oc)[2], float l) {
+        const int lane = lane_id(), h = lane >> 5;
+        const int q = blk * 32 + (lane & 31);
         const float inv = 1.0f / l;
-        bf16_t* dst = (bf16_t*)a.CTX + (row0 + min(q, Lb - 1)) * a.H + head * 64;
+        bf16_t* dstp = (bf16_t*)a.CTX + (g.row0 + min(q, g.Lb - 1)) * a.H + g.head * 64;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -920,122 +898,143 @@ __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(AttnArgs a) {
                     ov[i] = (__bf16)__uint_as_float(sw[0]);
                     ov[4 + i] = (__bf16)__uint_as_float(sw[1]);
                 }
-                if (q < Lb) *reinterpret_cast<float4*>(dst + d * 32 + 8 * (rq + h)) = __builtin_bit_cast(float4, ov);
+                if (q < g.Lb) *reinterpret_cast<float4*>(dstp + d * 32 + 8 * (rq + h)) = __builtin_bit_cast(float4, ov);
             }
     };
 
-    f32x16 s[2][2];      // scores of the unit being exponentiated / being produced, by block parity
-    bf16x8 p[2][4];      // P operand of the unit before / of this unit, by block parity
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) p[1][i][j] = (__bf16)0.0f;   // "unit -1": adds nothing
-
-    tile_landed(0);
-    if (!active) {   // a wave without queries only takes part in the barriers
-        for (int t = 1; t < nt; ++t) tile_landed(t);
-        return;
+    // --- the items of this workgroup ------------------------------------------------------------------------
+    int it = blockIdx.x;
+    if (it >= n_items) return;
+    AttnItem cur = geom(it);
+    f32x4v qf[2][4];
+    issue_bias(cur);
+    issue_q(cur, qf);
+    {
+        u32 voff[2];
+        piece_offsets(voff);
+        for (int t = 0; t < cur.nt; ++t) issue_tile(cur, t, voff);
     }
-#if defined(ATTN_ABL) && ATTN_ABL == 1   // ablation: fill only
-    for (int t = 1; t < nt; ++t) tile_landed(t);
-    return;
+#ifdef ATTN_STAMP
+    unsigned long long st_[8][6];
+    int sti_ = 0;
+#define STAMP(k) do { if (sti_ < 8) st_[sti_][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k) do {} while (0)
 #endif
-    qk(0, qf[0], s[0]);
-    for (int t = 0; t < nt; ++t) {
-        const bool more = t + 1 < nt;
-        if (more) tile_landed(t + 1);
-#if defined(ATTN_ABL) && ATTN_ABL == 3   // ablation: prologue, barriers, ONE tile and the store
-        if (t > 0) continue;
-#endif
-        const int tn = more ? t + 1 : t;    // (no next tile: the last one again, result unused)
-        const int tp = t > 0 ? t - 1 : 0;   // (no previous tile: P is zero)
-        stage(t, qf[1], s[1], tp, p[1], o[3], s[0], lsum[0], p[0]);   // unit (t, 0)
-        stage(t, qf[2], s[0], t, p[0], o[0], s[1], lsum[1], p[1]);    // unit (t, 1)
-        stage(t, qf[3], s[1], t, p[1], o[1], s[0], lsum[2], p[0]);    // unit (t, 2)
-        stage(tn, qf[0], s[0], t, p[0], o[2], s[1], lsum[3], p[1]);   // unit (t, 3)
-    }
-    pv(nt - 1, p[1], o[3]);
+    for (;;) {
+        // the last tiles, the bias and the query rows of `cur` were issued a moment ago (its first tiles long before)
+        STAMP(0);
+        fill_landed();
+        STAMP(1);
+        const int nxt = it + (int)gridDim.x;
+        const bool has_next = nxt < n_items;
+        const AttnItem nx = geom(has_next ? nxt : it);
+        // which tiles hold a masked key (bias values are 0 or -1e30)
+        unsigned maskbits = 0;
+        for (int t = 0; t < cur.nt; ++t)
+            if (__ballot(reinterpret_cast<const float*>(sBias)[t * 64 + lane_id()] != 0.0f) != 0ull) maskbits |= 1u << t;
+        u32 voff[2];
+        piece_offsets(voff);
+        lds_offsets();
 
-    // accept a block iff all its row sums are of sane magnitude; else recompute it the safe way
-    bool good[4];
+        f32x16 o[2][2];
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb) {
-        float l = lsum[qb];
-        const u32x2v sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
-        l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-        lsum[qb] = l;
-        good[qb] = __ballot(!(l > 1e-30f && l < 1e30f)) == 0ull;
-    }
-#pragma unroll
-    for (int qb = 0; qb < 4; ++qb)
-        if (good[qb]) store_block(qb, o[qb], lsum[qb]);
-    if (good[0] && good[1] && good[2] && good[3]) return;
-
-    // safe path: online softmax with a running maximum, one block at a time (rows with every key masked come out as
-    // the mean over those keys, as in attn_kernel)
-    auto safe_block = [&](int qb, const f32x4v(&qv)[4]) {
-        f32x16 os[2], ss[2];
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) os[d][r] = 0.0f;
-        float mrun = -INFINITY, lrun = 0.0f;
-        for (int t = 0; t < nt; ++t) {
-            qk(t, qv, ss);
-            float mx = -INFINITY;
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, ss[sub][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mnew = fmaxf(mrun, mx);
-            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-            float psum = 0.0f;
-            bf16x8 pb[4];
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(ss[sub][r] - mnew);
-                    psum += e;
-                    pb[sub * 2 + (r >> 3)][r & 7] = (__bf16)e;
-                }
-            lrun = lrun * alpha + psum;
-            mrun = mnew;
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int d = 0; d < 2; ++d)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) os[d][r] *= alpha;
-            pv(t, pb, os);
+                for (int r = 0; r < 16; ++r) o[i][d][r] = 0.0f;
+        float lsum[2] = {0.0f, 0.0f};   // this lane's half of a row sum
+        f32x16 s[2][2];                 // scores of this wave's block 0 / block 1
+        bf16x8 p[2][4];                 // P operand of block 0 / block 1
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[1][i][j] = (__bf16)0.0f;   // "the unit before the first": adds nothing
+
+        qk(0, qf[0], s[0]);
+        STAMP(2);
+        for (int t = 0; t < cur.nt; ++t) {
+            if (t > 0) barrier();   // every wave is through iteration t - 1 ...
+            // ... whose first stage was the last reader of tile t - 2 (its V; its K was last read in iteration t - 2):
+            // the next item's tile t - 2 streams into that slot while this item is being computed
+            if (has_next && t >= 2 && t - 2 < nx.nt) issue_tile(nx, t - 2, voff);
+            const int tn = t + 1 < cur.nt ? t + 1 : t;   // (no next tile: the last one again, result unused)
+            const int tp = t > 0 ? t - 1 : 0;            // (no previous tile: P is zero)
+            // unit (t, 0): beside the scores of (t, 1) and the context products of (t - 1, 1)
+            stage(t, (maskbits >> t) & 1u, qf[1], s[1], tp, p[1], o[1], s[0], lsum[0], p[0]);
+            // unit (t, 1): beside the scores of (t + 1, 0) and the context products of (t, 0)
+            stage(tn, (maskbits >> tn) & 1u, qf[0], s[0], t, p[0], o[0], s[1], lsum[1], p[1]);
         }
-        lrun += __shfl_xor(lrun, 32);
-        store_block(qb, os, lrun);
-    };
-    if (!good[0]) safe_block(0, qf[0]);
-    if (!good[1]) safe_block(1, qf[1]);
-    if (!good[2]) safe_block(2, qf[2]);
-    if (!good[3]) safe_block(3, qf[3]);
+        pv(cur.nt - 1, p[1], o[1]);
+        STAMP(3);
+
+        // accept a block iff all its row sums are of sane magnitude; the others are flagged for attn_kernel
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float l = lsum[i];
+            const u32x2v sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
+            l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            const bool good = __ballot(!(l > 1e-30f && l < 1e30f)) == 0ull;
+            if (lane_id() == 0) a.flags[(size_t)it * 16 + 8 * i + wave] = good ? 0 : 1;
+            if (good) store_block(cur, 8 * i + wave, o[i], l);
+        }
+        STAMP(4);
+#ifdef ATTN_STAMP
+        if (!has_next) { ++sti_; break; }
+#else
+        if (!has_next) break;
+#endif
+        barrier();   // every wave is done with the LDS image of `cur`
+        piece_offsets(voff);
+        for (int t = cur.nt >= 2 ? cur.nt - 2 : 0; t < nx.nt; ++t) issue_tile(nx, t, voff);
+        issue_bias(nx);
+        issue_q(nx, qf);
+        STAMP(5);
+#ifdef ATTN_STAMP
+        ++sti_;
+#endif
+        cur = nx;
+        it = nxt;
+    }
+#ifdef ATTN_STAMP
+    if ((blockIdx.x == 0 || blockIdx.x == 100) && threadIdx.x == 0 && a.B >= 64) {
+        static __device__ int once_[2];
+        if (atomicAdd(&once_[blockIdx.x == 0 ? 0 : 1], 1) == 20)
+            for (int i = 0; i < sti_ && i < 8; ++i)
+                printf("wg %d item %d: wait %llu qk0 %llu loop %llu store %llu issue %llu (cycles)\n", (int)blockIdx.x, i,
+                       st_[i][1] - st_[i][0], st_[i][2] - st_[i][1], st_[i][3] - st_[i][2], st_[i][4] - st_[i][3],
+                       i + 1 < sti_ ? st_[i][5] - st_[i][4] : 0ull);
+    }
+#endif
 }
 
 int launch_attn_bf16(const AttnArgs& a, hipStream_t st) {
-    const int nt = a.Lp >> 6;
-    const int lds = 2 * nt * 8192 + nt * 256;
     static const bool old_kernel = [] {
-        const char* v = getenv("OTTER_ATTN_OLD");   // A/B switch: the round-2 kernel (expects unscaled queries: only
-        return v && v[0] == '1';                    // meaningful for timing)
+        const char* v = getenv("OTTER_ATTN_OLD");   // A/B switch: the round-2 kernel
+        return v && v[0] == '1';
     }();
-    if (!old_kernel) {
+    if (!old_kernel && a.flags) {
+        // persistent: one workgroup per CU walks (batch, head) items; the blocks it rejects (see the kernel's header)
+        // are recomputed by the plain online-softmax kernel, whose workgroups exit at once when nothing is flagged
+        const int lds = 131072 + 8 * 256;
+        const int items = a.B * a.heads;
         OTTER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pipe_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(attn_pipe_kernel, dim3(a.heads, a.B), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(attn_pipe_kernel, dim3(items < a.ncu ? items : a.ncu), dim3(512), lds, st, a);
+        hipLaunchKernelGGL(attn_kernel<bf16_t>, dim3((a.L + 127) / 128, a.heads, a.B), dim3(256), 0, st, a);
         OTTER_HIP_TRY(hipGetLastError());
         return OTTER_OK;
     }
+    const int nt = a.Lp >> 6;
+    const int lds = 2 * nt * 8192 + nt * 256;
     // 8 waves x 64 queries.  (A 16-wave x 32-query form exists as attn_full_kernel<1>; it needs 128 registers per
     // lane, spills, and is not launched: a kernel whose hidden asynchronous loads land in registers must not spill.)
+    AttnArgs b = a;
+    b.flags = nullptr;
     OTTER_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_full_kernel<2>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(attn_full_kernel<2>, dim3(a.heads, a.B), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(attn_full_kernel<2>, dim3(a.heads, a.B), dim3(512), lds, st, b);
     OTTER_HIP_TRY(hipGetLastError());
     return OTTER_OK;
 }
@@ -1357,6 +1356,7 @@ struct otter_encoder {
     otter::DevBuf X, X1, QKV, CTX, TMP, MID, pos, kbias;
     otter::DevBuf part, stat1, stat2;   // LayerNorm statistics of the fused bf16 path
     otter::DevBuf seq;                  // packed batches: seq_len[B], seq_off[B], info[2]
+    otter::DevBuf aflags;               // attention: blocks attn_pipe_kernel rejected, [B][heads][16] bytes
     bool ln_fused = false;
     // attn_kernel's score scale.  fp32: 1/sqrt(64).  bf16: the query projection is stored pre-multiplied by
     // (1/sqrt(64)) log2(e) (attn_pipe_kernel exponentiates its scores in base 2 as they come out of the MFMA chain),
@@ -1511,6 +1511,7 @@ int ensure_ws(otter_encoder* e, int B, int L) {
     const long long rows = round_up64(M, 256) + 64;
     int rc0 = e->kbias.reserve((size_t)B * round_up(L, 64) * sizeof(float));   // [B][Lp], fully written by prep_kernel
     if (rc0) return rc0;
+    if ((rc0 = e->aflags.reserve((size_t)B * e->cfg.num_attention_heads * 16))) return rc0;   // fully written per launch
     if (rows <= e->ws_rows) return OTTER_OK;
     const size_t H = e->cfg.hidden_size, I = e->cfg.intermediate_size, es = esize(e->dtype);
     int rc;
@@ -1580,9 +1581,11 @@ int run_layers_nv(otter_encoder* e, const int64_t* ids, const int64_t* mask, con
         a.QKV = e->QKV.p; a.CTX = e->CTX.p; a.kbias = (const float*)e->kbias.p;
         a.B = B; a.L = L; a.Lp = Lp; a.H = H; a.heads = c.num_attention_heads;
         a.scale = e->attn_scale;
+        a.flags = (unsigned char*)e->aflags.p; a.ncu = e->ncu;
         if (sizeof(T) == 2 && L <= 512) {
             if ((rc = launch_attn_bf16(a, st))) return rc;
         } else {
+            a.flags = nullptr;   // every block
             hipLaunchKernelGGL(attn_kernel<T>, dim3((L + 127) / 128, c.num_attention_heads, B), dim3(256), 0, st, a);
             OTTER_HIP_TRY(hipGetLastError());
         }
@@ -1664,9 +1667,11 @@ int run_layers_fused(otter_encoder* e, const int64_t* ids, const int64_t* mask, 
         a.B = B; a.L = L; a.Lp = Lp; a.H = H; a.heads = c.num_attention_heads;
         a.scale = e->attn_scale;
         a.seq_off = seq_off; a.seq_len = seq_len;
+        a.flags = (unsigned char*)e->aflags.p; a.ncu = e->ncu;
         if (L <= 512) {
             if ((rc = launch_attn_bf16(a, st))) return rc;
         } else {
+            a.flags = nullptr;   // every block
             hipLaunchKernelGGL(attn_kernel<T>, dim3((L + 127) / 128, c.num_attention_heads, B), dim3(256), 0, st, a);
             OTTER_HIP_TRY(hipGetLastError());
         }
@@ -1977,7 +1982,7 @@ void otter_encoder_destroy(otter_encoder* e) {
     for (void* p : e->owned) (void)hipFree(p);
     e->X.release(); e->X1.release(); e->QKV.release(); e->CTX.release();
     e->TMP.release(); e->MID.release(); e->pos.release(); e->kbias.release();
-    e->part.release(); e->stat1.release(); e->stat2.release(); e->seq.release();
+    e->part.release(); e->stat1.release(); e->stat2.release(); e->seq.release(); e->aflags.release();
     delete e;
 }
 
