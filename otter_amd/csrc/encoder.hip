@@ -1010,10 +1010,18 @@ __global__ __launch_bounds__(512, 2) void attn_pipe_kernel(AttnArgs a) {
 }
 
 int launch_attn_bf16(const AttnArgs& a, hipStream_t st) {
-    static const bool old_kernel = [] {
-        const char* v = getenv("OTTER_ATTN_OLD");   // A/B switch: the round-2 kernel
-        return v && v[0] == '1';
-    }();
+    // switches for A/B runs and tests, read per call: OTTER_ATTN_OLD=1 the round-2 kernel, OTTER_ATTN_SAFE=1 the plain
+    // online-softmax kernel on every block (what the repair pass runs on the blocks attn_pipe_kernel rejects)
+    const char* ev = getenv("OTTER_ATTN_OLD");
+    const bool old_kernel = ev && ev[0] == '1';
+    ev = getenv("OTTER_ATTN_SAFE");
+    if (ev && ev[0] == '1') {
+        AttnArgs b = a;
+        b.flags = nullptr;
+        hipLaunchKernelGGL(attn_kernel<bf16_t>, dim3((a.L + 127) / 128, a.heads, a.B), dim3(256), 0, st, b);
+        OTTER_HIP_TRY(hipGetLastError());
+        return OTTER_OK;
+    }
     if (!old_kernel && a.flags) {
         // persistent: one workgroup per CU walks (batch, head) items; the blocks it rejects (see the kernel's header)
         // are recomputed by the plain online-softmax kernel, whose workgroups exit at once when nothing is flagged
