@@ -347,14 +347,37 @@ def free_port():
     return p
 
 
+def count_gpus_sysfs():
+    """GPUs of this machine from the kfd topology (nodes with SIMDs; CPU nodes have simd_count 0), WITHOUT any HIP or
+    torch.cuda call: the process that spawns the ranks must never have touched the GPU.  None if unreadable."""
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    for path in nodes:
+        try:
+            with open(path) as f:
+                for ln in f:
+                    if ln.startswith("simd_count") and int(ln.split()[1]) > 0:
+                        n += 1
+        except (OSError, ValueError, IndexError):
+            return None
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+    if vis:
+        n = min(n, len([v for v in vis.split(",") if v.strip()]))
+    return n
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` outside a launcher: start the N ranks as children of a
-    torch.distributed.run child process and pass its exit code on.  This process has not touched the GPU
-    (no HIP call yet; torch.cuda.device_count() does not initialise it on this image)."""
+    torch.distributed.run child process and pass its exit code on.  This process never touches the GPU: no HIP
+    call, no torch.cuda.* call (the device count comes from sysfs; if that cannot be read the check is left to
+    the ranks, which fail loudly on their own)."""
     rehearse = os.environ.get("OTTER_BENCH_REHEARSE") == "1"
     if not rehearse:
-        have = torch.cuda.device_count()
-        if have < n:
+        have = count_gpus_sysfs()
+        if have is not None and have < n:
             print("bench.py: --gpus %d but only %d GPU(s) visible (OTTER_BENCH_REHEARSE=1 runs every rank on GPU 0 "
                   "with a gloo exchange)" % (n, have), file=sys.stderr)
             return 2

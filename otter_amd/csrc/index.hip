@@ -19,6 +19,9 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -2592,6 +2595,50 @@ int next_pow2(int x) {
 
 }  // namespace
 
+// One persistent host thread per shard of otter_sharded_search (created at the shard's first sharded search, joined by
+// otter_index_destroy): a search may wait for its GPU (proof read-back), and the GPUs must not wait for each other;
+// creating and joining G - 1 threads on EVERY call cost as much as a one-query search.
+struct ShardWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> task;
+    bool has_task = false, done = true, quit = false;
+    void loop() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return has_task || quit; });
+            if (quit) return;
+            std::function<void()> t = std::move(task);
+            has_task = false;
+            lk.unlock();
+            t();
+            lk.lock();
+            done = true;
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<void()> t) {
+        std::lock_guard<std::mutex> lk(m);
+        task = std::move(t);
+        has_task = true;
+        done = false;
+        cv.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return done; });
+    }
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+            cv.notify_all();
+        }
+        if (th.joinable()) th.join();
+    }
+};
+
 struct otter_index {
     int d = 0, ld = 0, dtype = OTTER_F32, device = 0, ncu = 256;
     long long n = 0, cap_rows = 0, id_base = 0;
@@ -2623,6 +2670,7 @@ struct otter_index {
     // otter_sharded_search: this shard's own stream and staging (queries in, candidates out); on shards[0] also
     // the gathered candidates of every shard and the levels of a hierarchical merge
     hipStream_t sh_stream = nullptr;
+    ShardWorker* sh_worker = nullptr;
     otter::DevBuf sh_q, sh_D, sh_I, sh_gD, sh_gI, sh_tD, sh_tI;
 };
 
@@ -3789,6 +3837,10 @@ void otter_index_destroy(otter_index* ix) {
     ix->io_D.release();
     ix->io_I.release();
     if (ix->h_flag) (void)hipHostFree(ix->h_flag);
+    if (ix->sh_worker) {
+        ix->sh_worker->stop();
+        delete ix->sh_worker;
+    }
     if (ix->sh_stream) (void)hipStreamDestroy(ix->sh_stream);
     for (otter::DevBuf* b : {&ix->sh_q, &ix->sh_D, &ix->sh_I, &ix->sh_gD, &ix->sh_gI, &ix->sh_tD, &ix->sh_tI}) b->release();
     delete ix;
@@ -3883,37 +3935,64 @@ int otter_sharded_search(otter_index* const* shards, int G, const void* q, int64
     if (G == 1) return otter_index_search(h0, q, nq, k, D, I, io_is_device, stream);
     if ((rc = h0->sh_gD.reserve((size_t)G * nk * sizeof(float)))) return rc;
     if ((rc = h0->sh_gI.reserve((size_t)G * nk * sizeof(long long)))) return rc;
-    // peer copies go GPU to GPU over xGMI where the pair allows it (otherwise HIP stages them through the host)
-    for (int g = 1; g < G; ++g) {
-        const int dv = shards[g]->device;
-        int can = 0;
-        if (dv != home && hipDeviceCanAccessPeer(&can, home, dv) == hipSuccess && can) {
-            (void)hipDeviceEnablePeerAccess(dv, 0);          // "already enabled" is fine
-            (void)hipGetLastError();
-            DeviceGuard pg(dv);
-            if (pg.ok) { (void)hipDeviceEnablePeerAccess(home, 0); (void)hipGetLastError(); }
+    // peer copies go GPU to GPU over xGMI where the pair allows it (otherwise HIP stages them through the host);
+    // a pair is asked for and enabled once per process
+    {
+        static std::mutex peer_m;
+        static bool peer_done[64][64] = {};
+        std::lock_guard<std::mutex> lk(peer_m);
+        for (int g = 1; g < G; ++g) {
+            const int dv = shards[g]->device;
+            if (dv == home || dv < 0 || dv >= 64 || home >= 64 || peer_done[home][dv]) continue;
+            peer_done[home][dv] = true;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, home, dv) == hipSuccess && can) {
+                (void)hipDeviceEnablePeerAccess(dv, 0);          // "already enabled" is fine
+                (void)hipGetLastError();
+                DeviceGuard pg(dv);
+                if (pg.ok) { (void)hipDeviceEnablePeerAccess(home, 0); (void)hipGetLastError(); }
+            }
         }
     }
     // device queries: whatever produces them on the caller's stream has to be done before other GPUs read them
     if (io_is_device) OTTER_HIP_TRY(hipStreamSynchronize(st));
-    // one host thread per shard: a search may wait for its GPU (proof read-back), and the GPUs must not wait
-    // for each other
-    std::vector<int> rcs((size_t)G, OTTER_OK);
-    std::vector<std::string> msgs((size_t)G);
+    // shards 1 .. G-1 on their own persistent host threads, shard 0 here.  Nothing may throw across the C ABI: a
+    // shard whose thread cannot be created (or whose task cannot be queued) is searched inline instead.
+    int rcs[64];
+    char msgs[64][256];
+    bool queued[64] = {};
+    for (int g = 0; g < G; ++g) { rcs[g] = OTTER_OK; msgs[g][0] = 0; }
     auto run = [&](int g) {
         rcs[g] = sharded_search_one(shards[g], home, q, io_is_device, nq, k, (float*)h0->sh_gD.p + (size_t)g * nk,
                                     (long long*)h0->sh_gI.p + (size_t)g * nk);
-        if (rcs[g]) msgs[g] = otter::err_buf();
+        if (rcs[g]) snprintf(msgs[g], sizeof(msgs[g]), "%s", otter::err_buf());
     };
-    {
-        std::vector<std::thread> th;
-        th.reserve((size_t)G - 1);
-        for (int g = 1; g < G; ++g) th.emplace_back(run, g);
-        run(0);
-        for (auto& t : th) t.join();
+    for (int g = 1; g < G; ++g) {
+        otter_index* ix = shards[g];
+        try {
+            if (!ix->sh_worker) {
+                ShardWorker* w = new ShardWorker();
+                try {
+                    w->th = std::thread([w] { w->loop(); });
+                } catch (...) {
+                    delete w;
+                    throw;
+                }
+                ix->sh_worker = w;
+            }
+            ix->sh_worker->submit([&run, g] { run(g); });
+            queued[g] = true;
+        } catch (...) {
+            queued[g] = false;
+        }
+    }
+    run(0);
+    for (int g = 1; g < G; ++g) {
+        if (queued[g]) shards[g]->sh_worker->wait();
+        else run(g);
     }
     for (int g = 0; g < G; ++g)
-        if (rcs[g]) return set_err(rcs[g], "sharded_search: shard %d (device %d): %s", g, shards[g]->device, msgs[g].c_str());
+        if (rcs[g]) return set_err(rcs[g], "sharded_search: shard %d (device %d): %s", g, shards[g]->device, msgs[g]);
     // G-way merge on the home GPU, hierarchical when G * k exceeds one workgroup's select
     float* oD = D;
     int64_t* oI = I;

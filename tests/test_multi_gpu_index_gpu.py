@@ -120,3 +120,44 @@ def test_eval_driver_builds_the_multi_gpu_index(tmp_path):
     assert np.array_equal(I1, Im) and np.array_equal(D1, Dm)
     one.close()
     multi.close()
+
+
+def test_one_query_calls_on_four_shards_have_small_host_overhead():
+    """The reference's call pattern -- one query per search() call -- through otter_sharded_search: the per-call host
+    work (persistent shard threads, peer access asked for once, staging reused, the merge) must stay small beside the
+    searches.  1,000 consecutive calls on 4 shards.  This box has ONE device, on which the four shard searches take
+    turns (each launch fills the chip), so the yardstick is four searches of a quarter-size index issued one after
+    the other from one thread, not one search of the whole index (printed beside it: with one GPU per shard that is
+    the comparison that counts)."""
+    import time
+    n, d, k, G = 1_000_000, 768, 100, 4
+    x = torch.randn(n, d, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7))
+    one = IndexFlatIP(d)
+    one.add(x)
+    quarter = IndexFlatIP(d)
+    quarter.add(x[: n // G])
+    multi = MultiGpuIndexFlatIP(d, devices=[0] * G)
+    multi.add(x)
+    q = torch.randn(1, d, device="cuda", generator=torch.Generator(device="cuda").manual_seed(8))
+    D1, I1 = one.search(q, k)
+    Dm, Im = multi.search(q, k)
+    assert torch.equal(I1, Im) and torch.equal(D1, Dm)
+
+    def timed(ix, calls):
+        for _ in range(20):
+            ix.search(q, k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            ix.search(q, k)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / calls
+
+    t_one, t_quarter, t_multi = timed(one, 1000), timed(quarter, 1000), timed(multi, 1000)
+    print("one index %.3f ms, quarter index %.3f ms, 4 shards on one device %.3f ms per call (%.2f x four quarter "
+          "searches in a row, %.2f x the one index)" % (t_one * 1e3, t_quarter * 1e3, t_multi * 1e3,
+                                                        t_multi / (G * t_quarter), t_multi / t_one))
+    assert t_multi <= 1.3 * G * t_quarter, (t_one, t_quarter, t_multi)
+    multi.close()
+    quarter.close()
+    one.close()
