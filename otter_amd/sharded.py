@@ -5,8 +5,9 @@ Replaces the reference's multi-GPU modes:
   * faiss.index_cpu_to_all_gpus (scripts/eval_ottqa_retrieval.py:110-112: replicas of the whole
     index) -> shard g holds rows [g*ceil(N/G), min(N, (g+1)*ceil(N/G))); every rank searches its
     shard for ALL queries (ids already global via id_base), then ONE all-gather of the packed
-    (id, score) candidates -- 12 bytes per candidate, [nq, k] per rank -- and a G-way merge on
-    every rank.  When the gathered candidates would be large (config 5: 16,384 queries x top-1000
+    (id, score) candidates, [nq, k] per rank -- 8 bytes per candidate: the float32 score and the
+    row's 32-bit index INSIDE its shard; the receiver adds the sender's id_base, which every rank
+    learnt once at add() -- and a G-way merge on every rank.  When the gathered candidates would be large (config 5: 16,384 queries x top-1000
     = 197 MB per rank, 1.57 GB gathered) the exchange is sliced by queries instead: one all-to-all
     hands rank r every shard's packed candidates for ITS ceil(nq/G) queries (point-to-point
     messages, one xGMI link each, no ring), rank r merges them, and one all-gather of the merged
@@ -36,22 +37,36 @@ def shard_range(n, world, rank):
 
 
 class PackedCandidates:
-    """One exchange buffer for `rows` x k candidates: int64 ids first (8-byte aligned), float32
-    scores behind them -- 12 bytes per candidate, one collective instead of two.  D and I are views:
-    a search that takes output tensors writes straight into the send buffer."""
+    """One exchange buffer for `rows` x k candidates: ids first, float32 scores behind them, one
+    collective instead of two.  id_bytes = 8: int64 global ids (12 bytes per candidate; a search that
+    takes output tensors writes straight into the send buffer); id_bytes = 4: int32 indexes local to
+    the sending shard, -1 = missing (8 bytes per candidate).  D and I are views."""
 
-    def __init__(self, rows, k, device, lead=()):
-        self.rows, self.k = int(rows), int(k)
-        self.nbytes = (self.rows * self.k * 12 + 15) // 16 * 16     # 16-byte multiple: slices of a [G, nbytes] buffer stay aligned
+    def __init__(self, rows, k, device, lead=(), id_bytes=8):
+        self.rows, self.k, self.id_bytes = int(rows), int(k), int(id_bytes)
+        per = self.id_bytes + 4
+        self.nbytes = (self.rows * self.k * per + 15) // 16 * 16     # 16-byte multiple: slices of a [G, nbytes] buffer stay aligned
         self.buf = torch.empty(tuple(lead) + (self.nbytes,), dtype=torch.uint8, device=device)
 
     def views(self, buf=None):
         b = self.buf if buf is None else buf
-        cut = self.rows * self.k * 8
+        cut = self.rows * self.k * self.id_bytes
         lead = b.shape[:-1]
-        I = b[..., :cut].view(torch.int64).view(lead + (self.rows, self.k))
+        I = b[..., :cut].view(torch.int64 if self.id_bytes == 8 else torch.int32).view(lead + (self.rows, self.k))
         D = b[..., cut:cut + self.rows * self.k * 4].view(torch.float32).view(lead + (self.rows, self.k))
         return D, I
+
+
+def to_local_ids(I, base):
+    """int64 global ids -> int32 indexes inside the shard starting at `base` (-1 stays -1)."""
+    return torch.where(I >= 0, I - int(base), I).to(torch.int32)
+
+
+def to_global_ids(I32, bases):
+    """[G, rows, k] int32 shard-local indexes -> int64 global ids, bases[g] added to list g (-1 stays -1)."""
+    I = I32.to(torch.int64)
+    b = bases.to(I.device).view((-1,) + (1,) * (I.dim() - 1))
+    return torch.where(I >= 0, I + b, I)
 
 
 class ShardedIndexFlatIP:
@@ -69,10 +84,14 @@ class ShardedIndexFlatIP:
     SLICED_FROM_BYTES = 64 << 20
 
     def __init__(self, d, group=None, device=None, index_factory=None, merge_fn=None, exchange="auto",
-                 exchange_device=None, dtype="fp32"):
+                 exchange_device=None, dtype="fp32", compact=True):
         if exchange not in ("auto", "gather", "sliced"):
             raise ValueError("exchange must be 'auto', 'gather' or 'sliced'")
         self.exchange = exchange
+        # compact: 8 bytes per candidate on the wire (score + 32-bit shard-local index) instead of 12 (score + int64
+        # global id); shards of 2^31 rows or more fall back to 12
+        self.compact = bool(compact)
+        self.bases = None              # [G] int64: first global id of every rank's shard
         self.exchange_device = None if exchange_device is None else torch.device(exchange_device)
         self.d = int(d)
         self.group = group
@@ -106,6 +125,8 @@ class ShardedIndexFlatIP:
         if self.hi > self.lo:
             self.local.add(x[self.lo:self.hi])
         self.ntotal = n
+        self.bases = torch.tensor([shard_range(n, self.world, r)[0] for r in range(self.world)], dtype=torch.int64)
+        self._max_shard = max(shard_range(n, self.world, r)[1] - shard_range(n, self.world, r)[0] for r in range(self.world))
 
     def add_shard(self, x_local, id_base, ntotal):
         """This rank's rows are already local (e.g. just written by encode_rows): global ids are
@@ -115,6 +136,17 @@ class ShardedIndexFlatIP:
         if x_local.shape[0]:
             self.local.add(x_local)
         self.ntotal = int(ntotal)
+        # every rank learns every shard's first id and size once (the receiver of a compact exchange adds the base)
+        mine = torch.tensor([self.lo, self.hi - self.lo], dtype=torch.int64)
+        if self.world > 1:
+            dev = self.device if (self.device is not None and self.exchange_device is None) else torch.device("cpu")
+            allb = torch.empty((self.world * 2,), dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(allb, mine.to(dev), group=self.group)
+            allb = allb.cpu().view(self.world, 2)
+        else:
+            allb = mine.view(1, 2)
+        self.bases = allb[:, 0].contiguous()
+        self._max_shard = int(allb[:, 1].max())
 
     def _local_search(self, q, k):
         """(D, I) torch tensors [nq, k] of this rank's shard, on the device the collective will use."""
@@ -142,7 +174,8 @@ class ShardedIndexFlatIP:
             if mode == "auto":
                 mode = "sliced" if self.world * nq * kk * 12 >= self.SLICED_FROM_BYTES else "gather"
             self.last_exchange = mode
-            if mode == "gather" and self.device is not None and self.exchange_device is None:
+            compact = self.compact and self._max_shard < (1 << 31)
+            if mode == "gather" and not compact and self.device is not None and self.exchange_device is None:
                 # the HIP search writes (D, I) straight into the packed send buffer: no pack step
                 send = PackedCandidates(nq, kk, self.device)
                 Ds, Is = send.views()
@@ -150,21 +183,22 @@ class ShardedIndexFlatIP:
                 D, I = self._gather_packed(send)
             else:
                 D, I = self._local_search(q, kk)
-                D, I = self._exchange_sliced(D, I) if mode == "sliced" else self._exchange_gather(D, I)
+                idb = 4 if compact else 8
+                D, I = self._exchange_sliced(D, I, idb) if mode == "sliced" else self._exchange_gather(D, I, idb)
             if self.device is not None and D.device != self.device:
                 D, I = D.to(self.device), I.to(self.device)
         if as_numpy:
             return D.cpu().numpy(), I.cpu().numpy()
         return D, I
 
-    def _exchange_gather(self, D, I):
-        """One all-gather of the packed candidates (12 B x nq x k per rank: 2.66 MB at nq = 2214,
-        k = 100), then the G-way merge on every rank."""
+    def _exchange_gather(self, D, I, id_bytes=8):
+        """One all-gather of the packed candidates (8 B x nq x k per rank: 1.77 MB at nq = 2214,
+        k = 100; 12 B with int64 ids), then the G-way merge on every rank."""
         nq, kk = D.shape
-        send = PackedCandidates(nq, kk, D.device)
+        send = PackedCandidates(nq, kk, D.device, id_bytes=id_bytes)
         Ds, Is = send.views()
         Ds.copy_(D)
-        Is.copy_(I)
+        Is.copy_(to_local_ids(I, self.lo) if id_bytes == 4 else I)
         return self._gather_packed(send)
 
     def _gather_packed(self, send):
@@ -173,6 +207,8 @@ class ShardedIndexFlatIP:
         dist.all_gather_into_tensor(recv, send.buf, group=self.group)
         self.last_exchange_bytes = send.nbytes
         Dg, Ig = send.views(recv.view(G, send.nbytes))
+        if send.id_bytes == 4:
+            Ig = to_global_ids(Ig, self.bases)
         return self._merged(Dg, Ig)
 
     def _merged(self, Dg, Ig):
@@ -184,15 +220,19 @@ class ShardedIndexFlatIP:
             D, I = torch.from_numpy(D), torch.from_numpy(I)
         return D, I
 
-    def _exchange_sliced(self, D, I):
+    def _exchange_sliced(self, D, I, id_bytes=8):
         """SURVEY.md §8e option B.  Rank r owns queries [r*per, (r+1)*per), per = ceil(nq/G); rows past
-        nq are padding (score -FLT_MAX, id -1: the "missing" convention the merge already handles)."""
+        nq are padding (score -FLT_MAX, id -1: the "missing" convention the merge already handles).
+        The all-to-all carries this shard's candidates (shard-local 32-bit indexes when id_bytes = 4: every
+        received list g gets rank g's base added); the all-gather of the merged slices carries global ids."""
         G = self.world
         nq, kk = D.shape
         per = -(-nq // G)
         pad = per * G
+        if id_bytes == 4:
+            I = to_local_ids(I, self.lo)
         # chunk r of the send buffer = packed candidates of rank r's queries
-        send = PackedCandidates(per, kk, D.device, lead=(G,))
+        send = PackedCandidates(per, kk, D.device, lead=(G,), id_bytes=id_bytes)
         Ds, Is = send.views()
         for r in range(G):
             lo, hi = r * per, min(nq, (r + 1) * per)
@@ -205,6 +245,8 @@ class ShardedIndexFlatIP:
         recv = torch.empty_like(send.buf)
         dist.all_to_all_single(recv.view(-1), send.buf.view(-1), group=self.group)
         Dr, Ir = send.views(recv)                              # [G, per, kk]: every shard's list of MY queries
+        if id_bytes == 4:
+            Ir = to_global_ids(Ir, self.bases)
         Dm, Im = self._merged(Dr, Ir)
         mine = PackedCandidates(per, kk, D.device)
         Dv, Iv = mine.views()

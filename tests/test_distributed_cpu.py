@@ -39,7 +39,7 @@ def _merge(Dc, Ic):
     return torch.from_numpy(D), torch.from_numpy(I)
 
 
-def _worker(rank, world, initfile, n, outdir, exchange="auto"):
+def _worker(rank, world, initfile, n, outdir, exchange="auto", compact=True, via_add_shard=False):
     dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
     try:
         rng = np.random.RandomState(7)
@@ -47,10 +47,19 @@ def _worker(rank, world, initfile, n, outdir, exchange="auto"):
         xb[n // 2 + 3] = xb[5]                       # a cross-shard exact tie
         q = rng.randn(9, 64).astype(np.float32)
         k = 20
-        six = sharded.ShardedIndexFlatIP(64, index_factory=_OracleIndex, merge_fn=_merge, exchange=exchange)
-        six.add_global(xb)
+        six = sharded.ShardedIndexFlatIP(64, index_factory=_OracleIndex, merge_fn=_merge, exchange=exchange,
+                                         compact=compact)
+        if via_add_shard:
+            lo, hi = sharded.shard_range(n, world, rank)
+            six.add_shard(xb[lo:hi], lo, n)          # every rank learns the others' bases by one all-gather
+        else:
+            six.add_global(xb)
         assert six.ntotal == n and (six.lo, six.hi) == sharded.shard_range(n, world, rank)
+        assert six.bases.tolist() == [sharded.shard_range(n, world, r)[0] for r in range(world)]
         D, I = six.search(q, k)
+        if exchange == "gather":                     # 8 bytes per candidate on the wire (12 with int64 ids)
+            per = 8 if compact else 12
+            assert six.last_exchange_bytes == (9 * k * per + 15) // 16 * 16
         np.save(os.path.join(outdir, "D%d.npy" % rank), D.numpy())
         np.save(os.path.join(outdir, "I%d.npy" % rank), I.numpy())
 
@@ -70,12 +79,14 @@ def _worker(rank, world, initfile, n, outdir, exchange="auto"):
 
 # 7 rows < k: -1 padding survives the merge.  "sliced" = the all-to-all exchange by query slices
 # (9 queries over 2 or 3 ranks: ragged last slice, padded rows must not leak into the result)
-@pytest.mark.parametrize("n,world,exchange", [(101, 2, "gather"), (7, 2, "gather"), (101, 2, "sliced"),
-                                              (7, 2, "sliced"), (101, 3, "sliced")])
-def test_sharded_search_gloo(n, world, exchange):
+@pytest.mark.parametrize("n,world,exchange,compact,via_add_shard", [
+    (101, 2, "gather", True, False), (7, 2, "gather", True, False), (101, 2, "sliced", True, False),
+    (7, 2, "sliced", True, False), (101, 3, "sliced", True, False), (101, 3, "gather", True, True),
+    (101, 2, "gather", False, False), (101, 3, "sliced", False, True)])
+def test_sharded_search_gloo(n, world, exchange, compact, via_add_shard):
     with tempfile.TemporaryDirectory() as tmp:
         initfile = os.path.join(tmp, "init")
-        mp.spawn(_worker, args=(world, initfile, n, tmp, exchange), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, initfile, n, tmp, exchange, compact, via_add_shard), nprocs=world, join=True)
         rng = np.random.RandomState(7)
         xb = rng.randn(n, 64).astype(np.float32)
         xb[n // 2 + 3] = xb[5]
@@ -169,3 +180,15 @@ def test_sharded_search_with_numpy_queries_and_a_numpy_index():
     D2, I2 = pc.views(two)
     assert D2.shape == (2, 3, 5) and torch.equal(D2[1], D) and torch.equal(I2[0], I)
     assert pc.nbytes % 16 == 0 and pc.nbytes >= 15 * 12
+
+
+def test_compact_ids_round_trip():
+    I = torch.tensor([[5, 7, -1], [100, -1, -1]], dtype=torch.int64)
+    loc = sharded.to_local_ids(I, 5)
+    assert loc.dtype == torch.int32 and loc.tolist() == [[0, 2, -1], [95, -1, -1]]
+    both = torch.stack([loc, loc])
+    glob = sharded.to_global_ids(both, torch.tensor([5, 1000]))
+    assert glob.dtype == torch.int64 and glob[0].tolist() == I.tolist() and glob[1].tolist() == [[1000, 1002, -1], [1095, -1, -1]]
+    pc = sharded.PackedCandidates(2, 3, "cpu", id_bytes=4)
+    D, Iv = pc.views()
+    assert Iv.dtype == torch.int32 and pc.nbytes == (2 * 3 * 8 + 15) // 16 * 16
