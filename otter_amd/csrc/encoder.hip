@@ -363,7 +363,9 @@ __device__ __forceinline__ void dma4s(const void* sbase, u32 voff, u32 lds_dst) 
         : "memory");
 }
 
-__device__ __forceinline__ void wait_vmcnt_upto7(int n) {   // n in {0..7} or an even number <= 16
+__device__ __forceinline__ void wait_vmcnt_upto7(int n) {   // waits for AT MOST n outstanding: n rounded DOWN to a listed value
+    if (n > 16) n = 16;
+    if (n > 8) n &= ~1;
     switch (n) {
         case 0: wait_vmcnt<0>(); break;
         case 1: wait_vmcnt<1>(); break;
@@ -378,7 +380,7 @@ __device__ __forceinline__ void wait_vmcnt_upto7(int n) {   // n in {0..7} or an
         case 12: wait_vmcnt<12>(); break;
         case 14: wait_vmcnt<14>(); break;
         case 16: wait_vmcnt<16>(); break;
-        default: wait_vmcnt<14>(); break;   // (anything larger: waiting for more than asked is safe)
+        default: wait_vmcnt<0>(); break;    // (unreachable; waiting for everything is always safe)
     }
 }
 

@@ -2658,6 +2658,7 @@ struct otter_index {
     otter::DevBuf xh, xres2, xrmax, qh16, fb3_q, fb3_D, fb3_I;
     long long xh_rows = 0, xh_cap = 0;
     bool xh_failed = false, one_prod_off = false;
+    long long win_q[4] = {0, 0, 0, 0}, win_f[4] = {0, 0, 0, 0};   // small calls: queries seen / left unproven, per pass
     bool coarse_off = false;        // even the three-product pass left > 1/4 of a batch unproven (scores within rounding of each
                                     // other, e.g. near-duplicate rows): this corpus is searched by the exact kernel from then on
     long long last_stage0_unproven = 0;
@@ -3407,8 +3408,18 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
     OTTER_HIP_TRY(hipStreamSynchronize(st));
     const long long nf = *ix->h_flag;
     if (mode >= 2 && first) ix->last_refined += nf;
-    // (a verdict on the corpus needs a batch worth the name: one hard query of a one-query call is not one)
-    const bool verdict = nq >= 32 && nf * 4 > nq;
+    // (a verdict on the corpus needs a batch worth the name: one hard query of a one-query call is not one.  Small
+    // calls -- the reference issues ONE query per call -- are judged over a running window of 64 queries per pass,
+    // so a corpus whose proofs fail stops paying for the coarse pass there too)
+    bool verdict = nq >= 32 && nf * 4 > nq;
+    if (nq < 32 && first) {
+        ix->win_q[mode] += nq;
+        ix->win_f[mode] += nf;
+        if (ix->win_q[mode] >= 64) {
+            verdict = ix->win_f[mode] * 4 > ix->win_q[mode];
+            ix->win_q[mode] = ix->win_f[mode] = 0;
+        }
+    }
     if (mode == 3 && verdict) ix->one_prod_off = true;
     if (mode == 2 && verdict) ix->two_prod_off = true;
     if (mode == 1 && verdict) {
@@ -3760,6 +3771,7 @@ int otter_index_reset(otter_index* ix) {
     ix->two_prod_off = false;
     ix->one_prod_off = false;
     ix->coarse_off = false;
+    for (int m = 0; m < 4; ++m) ix->win_q[m] = ix->win_f[m] = 0;
     ix->xh_rows = 0;
     if (ix->xrmax.p) {
         DeviceGuard g2(ix->device);

@@ -60,16 +60,22 @@ class _PipeSlot:
             if t.is_cuda:                 # already resident: nothing to stage
                 out[name] = t
                 continue
-            src = t.to(torch.int64).contiguous() if t.dtype != torch.int64 else t.contiguous()
+            # integer and bool tensors (ids, masks) travel as int64, which is what the encoder takes; anything else
+            # keeps its own dtype, as move_to_cuda does (retrieval/utils/utils.py:31-48) -- never a silent truncation
+            if t.dtype == torch.int64 or t.is_floating_point() or t.is_complex():
+                src = t.contiguous()
+            else:
+                src = t.to(torch.int64).contiguous()
             if not self.use_cuda:
                 out[name] = src
                 continue
             n = src.numel()
-            pin = self._flat(self.pin, name, n, torch.int64, True)[:n].view(src.shape)
+            key = (name, src.dtype)
+            pin = self._flat(self.pin, key, n, src.dtype, True)[:n].view(src.shape)
             # (a plain memcpy: torch's copy_ fans 512 KB out over its thread pool, whose wake-up after an idle
             # phase was measured at up to 32 ms -- with nothing queued on the GPU behind it)
             np.copyto(pin.numpy(), src.numpy())
-            devt = self._flat(self.dev, name, n, torch.int64, False, device)[:n].view(src.shape)
+            devt = self._flat(self.dev, key, n, src.dtype, False, device)[:n].view(src.shape)
             with torch.cuda.stream(copy_stream):
                 devt.copy_(pin, non_blocking=True)
             out[name] = devt
