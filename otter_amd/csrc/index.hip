@@ -1992,7 +1992,7 @@ void launch_rescore(const RescoreArgs& ra, unsigned grid, hipStream_t st) {
 __global__ void margin_check_kernel(const float* Dexact, const float* Dcoarse, const long long* Icoarse,
                                     const float* qnorm2, const u32* xnorm2_max, float rel, long long nq, int k, int kc,
                                     long long n, u32* flags, u32* nflag, const float* qres2,
-                                    const u32* xres2_max) {
+                                    const u32* xres2_max, const u32* opt_thr) {
     const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (q >= nq) return;
     bool ok;
@@ -2007,6 +2007,10 @@ __global__ void margin_check_kernel(const float* Dexact, const float* Dcoarse, c
         // one product: q.x - q_hi.x_hi = (q - q_hi).x + q_hi.(x - x_hi), |q_hi| <= (1 + 2^-8) |q|
         if (xres2_max) eps += 1.005f * sqrtf(qnorm2[q]) * sqrtf(__uint_as_float(*xres2_max));
         ok = Icoarse[q * kc + kc - 1] >= 0 && ek > tc + eps;    // false on NaN / inf bounds
+        // the coarse scan started from an OPTIMISTIC threshold (a guess at the kc-th best score from a small sample):
+        // rows whose key lies below it were never looked at, so the coarse list is the true top kc only if its last
+        // entry reaches the threshold
+        if (opt_thr && f2key(tc) < opt_thr[q]) ok = false;
     }
     flags[q] = ok ? 0u : 1u;
     if (!ok) atomicAdd(nflag, 1u);
@@ -2087,6 +2091,8 @@ struct MergeArgs {
                          // may alias `out` (a workgroup has gathered its query's lists before it writes)
     const u32* ex_cnt;   // [nq_pad]
     u32* thr_out;        // non-final: [nq_pad] key of the k-th best, 0 if fewer than k
+    int thr_rank;        // 0: as above; r > 0: thr_out = key of the r-th best instead (0 if fewer than r) -- an OPTIMISTIC
+                         // threshold for a scan of many more rows, whose result the caller has to verify
     u32* zero_words;     // the stream kernel's arrival counter, ready flag and thresholds (ST_SYNC_WORDS), left zero; or null
 };
 
@@ -2336,7 +2342,20 @@ __global__ __launch_bounds__(NT) void merge_kernel(MergeArgs a) {
         }
         if (tid == 0) {
             a.out_cnt[q] = (u32)n;
-            if (a.thr_out) a.thr_out[q] = n >= k ? (u32)(Tmin >> 32) : 0u;
+            if (a.thr_out && a.thr_rank <= 0) a.thr_out[q] = n >= k ? (u32)(Tmin >> 32) : 0u;
+        }
+        if (a.thr_out && a.thr_rank > 0) {
+            // the r-th best of the <= k survivors by rank counting (composites are unique: exactly one has r - 1 above it)
+            if (n < a.thr_rank) {
+                if (tid == 0) a.thr_out[q] = 0u;
+            } else {
+                for (int t = tid; t < n; t += NT) {
+                    const u64 v = l[t];
+                    int r = 0;
+                    for (int j = 0; j < n; ++j) r += l[j] > v;
+                    if (r == a.thr_rank - 1) a.thr_out[q] = (u32)(v >> 32);
+                }
+            }
         }
     }
 }
@@ -2774,7 +2793,7 @@ int launch_merge(int device, const MergeArgs& ma, long long nq, hipStream_t st) 
 int run_merge(otter_index* ix, const u64* in, const u32* in_cnt, int cap_in, int S_in, long long nq, long long nq_pad,
               int k, bool final, float* D, long long* I, const u64* ex, const u32* ex_cnt, u64* list_out,
               u32* list_cnt, u32* thr_out, hipStream_t st, int take_first = 0, Scratch* sc = nullptr,
-              u32* zero_words = nullptr) {
+              u32* zero_words = nullptr, int thr_rank = 0) {
     (void)sc;
     const int take = take_first > 0 ? take_first : std::min(k, cap_in);
     MergeArgs ma;
@@ -2794,6 +2813,7 @@ int run_merge(otter_index* ix, const u64* in, const u32* in_cnt, int cap_in, int
     ma.ex = ex;
     ma.ex_cnt = ex_cnt;
     ma.thr_out = final ? nullptr : thr_out;
+    ma.thr_rank = thr_rank;
     ma.zero_words = zero_words;
     // Four waves per query (cheap barriers; the pool lives in registers during a select), pool sized to the
     // job: a smaller pool lets more workgroups share a CU's LDS.
@@ -3084,9 +3104,17 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
 // sample_tiles tiles are scanned by all workgroups first and merged; the key of each query's kk-th
 // best among them seeds every strip of the main scan.  Exact: the sample rows have the smallest ids,
 // so a later row that only ties that key ranks behind kk sample rows.
+// Optimistic start (*optimistic in/out; large batches of the one-product pass): instead of sample LEVELS that end at a
+// quarter of the corpus -- scanned at 1.5 ... 2x the main scan's cost per tile, because an epilogue is expensive while
+// more than ~1 % of the scores pass, with a merge after each -- ONE small level 0, whose merge hands out the key of
+// each query's r-th best sample row (r << kk) as the threshold of the scan of ALL other rows: a guess at the kk-th
+// best of the whole corpus, loose enough that it is almost never too high (the number of rows above it is about
+// r N / n0 with a relative spread of 1 / sqrt(r); strips that collect more than they can hold tighten their own
+// threshold exactly, as always).  The caller verifies: the list is the true top kk iff its kk-th entry reaches the
+// threshold (margin_check_kernel), and sends the others through the next pass like any unproven query.
 template <int MODE>
 int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int kk, float* Dc, long long* Ic,
-                     hipStream_t st, const void* Qk = nullptr) {
+                     hipStream_t st, const void* Qk = nullptr, bool* optimistic = nullptr) {
     Scan16Cfg cfg;
     int rc = pick_cfg16<MODE>(kk, &cfg);
     if (rc) return rc;
@@ -3108,7 +3136,33 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
     const int max_levels = lvl_env ? std::max(1, atoi(lvl_env)) : (qtiles >= 8 ? 3 : 2);
     const int cover = total_tiles / (frac_env ? std::max(2, atoi(frac_env)) : (qtiles >= 8 ? 4 : 8));
     int lv_tiles[8], nlv = 0, sample_tiles = 0;
-    if (!no_sample) {
+    static const char* opt_env = getenv("OTTER_OPT_THR");           // 0: off; r: rank of the optimistic threshold
+    static const char* opt_l0_env = getenv("OTTER_OPT_L0");         // tiles of its level 0
+    int opt_rank = 0;
+    if (optimistic && *optimistic && !no_sample && !(opt_env && atoi(opt_env) == 0)) {
+        // rows above the r-th best of n0 sample rows: about r N / n0 in the whole corpus, i.e. Gamma(r) N / n0 with the
+        // sample's fluctuation; asked for: >= kk, with a failure probability per query far below 1 / nq.  r = 12 and
+        // kk n0 / N <= 1.6: P(Gamma(12) < 1.6) ~ 1.4e-7.  Level 0 stays ONE tile per strip and <= 32 strips -- the
+        // uncompacted dump the first merge takes whole (more tiles would be scanned without any threshold, at three
+        // times a tile's steady-state cost: measured slower) -- so n0 <= 8192 rows, and the optimistic start applies
+        // while kk <= 1.6 N / n0 (k = 100 on a million rows: kk = 211, n0 = 7168 at 2214 queries; not k = 1000).
+        opt_rank = opt_env ? std::max(1, atoi(opt_env)) : 12;
+        int l0 = std::min(wgs, 32);
+        if (opt_l0_env) l0 = std::max(1, atoi(opt_l0_env));
+        const int l0_safe = (int)(1.6 * total_tiles / kk);
+        if (!opt_l0_env) l0 = std::min(l0, l0_safe);
+        // (measured, 1M x 768, k = 100, same box: 512 queries 1.02 -> 0.955 ms, 1024: 1.80 -> 1.71, 2214: 3.79 -> 3.68;
+        // 4096 queries -- 16 workgroups per query tile, a 4096-row sample, three times the survivors -- 6.44 -> 6.66:
+        // below 24 sample tiles the levels stay)
+        if ((l0 >= 24 || opt_l0_env) && l0 <= total_tiles / 8 && (long long)l0 * S16_BM >= 4ll * opt_rank && opt_rank <= kk) {
+            lv_tiles[nlv++] = l0;
+            sample_tiles = l0;
+        } else {
+            opt_rank = 0;
+        }
+    }
+    if (optimistic) *optimistic = opt_rank > 0;
+    if (!no_sample && opt_rank == 0) {
         int l0 = std::max(1, (int)((4ll * kk + (long long)wgs * S16_BM - 1) / ((long long)wgs * S16_BM))) * wgs;
         if (per_env) l0 = std::max(1, atoi(per_env)) * wgs;
         static const char* l0s_env = getenv("OTTER_SAMPLE_L0_STRIPS");   // tuning runs only: one-tile strips of level 0
@@ -3185,7 +3239,8 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
         // the list of the levels so far is merged in place with this level's strips
         if ((rc = run_merge(ix, (const u64*)ix->cand.p, (const u32*)ix->cnt.p, cfg.cap, sa.strips, nq, nq_pad, kk, false,
                             nullptr, nullptr, lv ? (const u64*)ix->smp.p : nullptr, lv ? (const u32*)ix->smpcnt.p : nullptr,
-                            (u64*)ix->smp.p, (u32*)ix->smpcnt.p, (u32*)ix->thr0.p, st, whole ? S16_BM : 0)))
+                            (u64*)ix->smp.p, (u32*)ix->smpcnt.p, (u32*)ix->thr0.p, st, whole ? S16_BM : 0, nullptr, nullptr,
+                            opt_rank)))
             return rc;
         done_tiles += lv_tiles[lv];
     }
@@ -3361,6 +3416,7 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
                            st, qd, (float*)ix->qpad.p, nq, nq_pad, ix->d, ix->ld);
     }
     OTTER_HIP_TRY(hipGetLastError());
+    bool optimistic = false;
     if (mode == 3) {
         static const char* no_stream16 = getenv("OTTER_NO_STREAM");
         if (nq <= 32 && kc <= 320 && !no_stream16) {
@@ -3369,7 +3425,9 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
             Scratch own;
             rc = search_chunk_stream(ix, qd, nq, kc, (float*)ix->cD.p, (long long*)ix->cI.p, st, &own, ix->qh16.p, ix->xh.p);
         } else {
-            rc = scan16_and_merge<0>(ix, ix->xh.p, ix->ld, nq, kc, (float*)ix->cD.p, (long long*)ix->cI.p, st, ix->qh16.p);
+            optimistic = nq >= 512;     // (few query tiles: short strips, the sample levels are cheap there)
+            rc = scan16_and_merge<0>(ix, ix->xh.p, ix->ld, nq, kc, (float*)ix->cD.p, (long long*)ix->cI.p, st, ix->qh16.p,
+                                     &optimistic);
         }
     } else if (mode == 2)
         rc = scan16_and_merge<2>(ix, ix->xs.p, 2 * ix->ld, nq, kc, (float*)ix->cD.p, (long long*)ix->cI.p, st);
@@ -3398,7 +3456,8 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
                        (const float*)ix->cD.p, (const long long*)ix->cI.p, (const float*)ix->qnorm2.p,
                        (const u32*)ix->xnmax.p, split_rel_eps(ix->d), nq, k, kc, ix->n, flags, flags + nq,
                        mode >= 2 ? (const float*)ix->qres2.p : (const float*)nullptr,
-                       mode == 3 ? (const u32*)ix->xrmax.p : (const u32*)nullptr);
+                       mode == 3 ? (const u32*)ix->xrmax.p : (const u32*)nullptr,
+                       optimistic ? (const u32*)ix->thr0.p : (const u32*)nullptr);
     OTTER_HIP_TRY(hipGetLastError());
     // the one host round trip of this pass (4 bytes): how many queries are left without a proof.  The
     // stream is synchronised here -- once per pass of a large-batch search (see include/otter_hip.h).
