@@ -3136,8 +3136,8 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
     const int max_levels = lvl_env ? std::max(1, atoi(lvl_env)) : (qtiles >= 8 ? 3 : 2);
     const int cover = total_tiles / (frac_env ? std::max(2, atoi(frac_env)) : (qtiles >= 8 ? 4 : 8));
     int lv_tiles[8], nlv = 0, sample_tiles = 0;
-    static const char* opt_env = getenv("OTTER_OPT_THR");           // 0: off; r: rank of the optimistic threshold
-    static const char* opt_l0_env = getenv("OTTER_OPT_L0");         // tiles of its level 0
+    const char* opt_env = getenv("OTTER_OPT_THR");                  // 0: off; r: rank of the optimistic threshold (read per call:
+    const char* opt_l0_env = getenv("OTTER_OPT_L0");                // tests force failures with r = 1); tiles of its level 0
     int opt_rank = 0;
     if (optimistic && *optimistic && !no_sample && !(opt_env && atoi(opt_env) == 0)) {
         // rows above the r-th best of n0 sample rows: about r N / n0 in the whole corpus, i.e. Gamma(r) N / n0 with the

@@ -216,3 +216,34 @@ def test_one_query_calls_also_switch_the_coarse_pass_off():
         redone.append(ix.last_fallback)
     assert sum(redone[:64]) > 16 and sum(redone[64:]) == 0, redone
     ix.close()
+
+
+def test_optimistic_threshold_failures_are_searched_again():
+    """Large batches start their coarse scan from an optimistic threshold (the 12th best of a small sample) and verify
+    afterwards.  Forced to fail here: rank 1 (the best sample score) is far above the true kc-th best, so nearly every
+    query misses candidates, is flagged by the check and goes through the next pass -- the result must still be the
+    oracle's, bit for bit; with the default rank nothing is refined."""
+    import os
+    from otter_amd.index import IndexFlatIP
+    rng = np.random.RandomState(11)
+    n, d, nq, k = 300000, 128, 600, 100
+    xb = rng.randn(n, d).astype(np.float32)
+    q = rng.randn(nq, d).astype(np.float32)
+    Dr, Ir = flat_ip.search_c(xb, q[:64], k, mode=flat_ip.MODE_GPU_ORDER)
+    ix = IndexFlatIP(d)
+    ix.add(xb)
+    D0, I0 = ix.search(q, k)
+    assert ix.last_refined == 0 and ix.last_fallback == 0
+    np.testing.assert_array_equal(I0[:64], Ir)
+    np.testing.assert_array_equal(D0[:64].view(np.uint32), Dr.view(np.uint32))
+    os.environ["OTTER_OPT_THR"] = "1"
+    os.environ["OTTER_OPT_L0"] = "28"
+    try:
+        D1, I1 = ix.search(q, k)
+        refined = ix.last_refined
+    finally:
+        del os.environ["OTTER_OPT_THR"], os.environ["OTTER_OPT_L0"]
+    assert refined > nq // 2, refined
+    np.testing.assert_array_equal(I1, I0)
+    np.testing.assert_array_equal(D1.view(np.uint32), D0.view(np.uint32))
+    ix.close()
