@@ -154,6 +154,17 @@ int otter_index_timing(otter_index* ix, double* scan_ms, int64_t* scan_launches)
  * so the exact kernel serves every batch instead of paying for coarse passes that prove nothing. */
 int otter_index_coarse_state(const otter_index* ix);
 
+/* HBM economy (no counterpart in the reference).  Besides its float32 rows an OTTER_F32 index builds, at its first
+ * search, bf16 planes for the coarse pass: planes = 2 (default) the hi/lo planes (the corpus' bytes again: two- and
+ * three-product passes, the fallbacks of large batches) AND the hi plane alone (half of them: the one-product pass
+ * every batch size starts with) -- 2.5x the corpus in all; planes = 1 the hi plane only -- 1.5x: a query the
+ * one-product pass cannot prove goes to the exact float32 kernels, which costs nothing on corpora whose proofs
+ * succeed (every corpus measured except near-duplicate rows) and is the right choice for a process that serves
+ * small query batches; planes = 0 none -- 1.0x: the exact float32 kernels serve everything (batches of 33 and more
+ * at about 1/6 of the rate).  Results are the same bits under every setting.  Planes no longer wanted are freed
+ * (the device is synchronised first); may be called at any time between searches. */
+int otter_index_set_planes(otter_index* ix, int planes);
+
 /* Diagnostic (no counterpart in the reference).  Large query batches on an OTTER_F32 index run a
  * coarse pass on the bf16 matrix cores (hi/lo split of both operands), re-score its k + margin
  * candidates with the exact float32 chain and PROVE per query that no other row can reach the top

@@ -48,6 +48,7 @@ SIGNATURES = {
     "otter_index_reset": (c_int, [c_vp]),
     "otter_index_set_id_base": (c_int, [c_vp, c_i64]),
     "otter_index_coarse_state": (c_int, [c_vp]),
+    "otter_index_set_planes": (c_int, [c_vp, c_int]),
     "otter_index_last_fallback": (c_i64, [c_vp]),
     "otter_index_last_refined": (c_i64, [c_vp]),
     "otter_index_destroy": (None, [c_vp]),

@@ -1795,20 +1795,28 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
 
 // |row - bf16(row)|^2 of fp32 rows [rows][ld] (one wave per row): what a product on rounded rows leaves out
 __global__ __launch_bounds__(256) void residual_norm_kernel(const float* __restrict__ src, long long rows, int ld,
-                                                            float* __restrict__ res2) {
+                                                            float* __restrict__ res2, float* __restrict__ nrm2) {
+    // nrm2 (optional): |x|^2 as well -- an index that keeps only the hi plane has no split_rows_kernel pass to take it from
     const int lane = threadIdx.x & 63;
     const long long w0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
     const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
     for (long long r = w0; r < rows; r += nw) {
-        float rr = 0.f;
+        float rr = 0.f, nn = 0.f;
         for (int c = lane; c < ld; c += 64) {
             const float v = src[r * ld + c];
             const float e = v - (float)(__bf16)v;
             rr += e * e;
+            nn += v * v;
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) rr += __shfl_xor(rr, o);
-        if (lane == 0) res2[r] = rr;
+        for (int o = 32; o > 0; o >>= 1) {
+            rr += __shfl_xor(rr, o);
+            nn += __shfl_xor(nn, o);
+        }
+        if (lane == 0) {
+            res2[r] = rr;
+            if (nrm2) nrm2[r] = nn;
+        }
     }
 }
 
@@ -2677,6 +2685,7 @@ struct otter_index {
     otter::DevBuf xh, xres2, xrmax, qh16, fb3_q, fb3_D, fb3_I;
     long long xh_rows = 0, xh_cap = 0;
     bool xh_failed = false, one_prod_off = false;
+    int planes = 2;                 // otter_index_set_planes: 0 none, 1 the bf16 hi plane only, 2 all (hi + hi/lo)
     long long win_q[4] = {0, 0, 0, 0}, win_f[4] = {0, 0, 0, 0};   // small calls: queries seen / left unproven, per pass
     bool coarse_off = false;        // even the three-product pass left > 1/4 of a batch unproven (scores within rounding of each
                                     // other, e.g. near-duplicate rows): this corpus is searched by the exact kernel from then on
@@ -2946,18 +2955,21 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
         // plane it saves is a few hundred megabytes -- 1M x 768 saves 1.5 GB = 0.15 ms; below, the exact stream kernels)
         const bool small_ok = nq > 32 || (!split_min_env && (long long)ix->n * ix->ld >= 200000000ll) || (split_min_env != nullptr);
         if (!no_split_env && !ix->no_split && !ix->coarse_off && nq >= split_min && small_ok && ix->n >= 65536 &&
-            split_kc(k, 1, ix->d) <= S16_MAX_K) {
-            const int rs = ensure_split_planes(ix, st);
+            split_kc(k, 1, ix->d) <= S16_MAX_K && ix->planes > 0) {
+            // planes == 1: only the hi plane exists (half the corpus' bytes instead of 1.5x): the one-product pass or
+            // nothing; what it cannot prove goes to the exact kernels
+            const int rs = ix->planes == 2 ? ensure_split_planes(ix, st) : 0;
             if (rs < 0) return rs;
             if (rs == 0) {
                 const int forced = mode_env ? atoi(mode_env) : 0;      // 1 / 2: start with that many products
-                int mode = 1;
-                if (forced != 1 && !ix->two_prod_off && split_kc(k, 2, ix->d) <= S16_MAX_K) mode = 2;
-                if (forced != 1 && forced != 2 && !ix->one_prod_off && split_kc(k, 3, ix->d) <= S16_MAX_K) {
+                int mode = ix->planes == 2 ? 1 : 0;
+                if (ix->planes == 2 && forced != 1 && !ix->two_prod_off && split_kc(k, 2, ix->d) <= S16_MAX_K) mode = 2;
+                if (((forced != 1 && forced != 2) || ix->planes == 1) && !ix->one_prod_off && split_kc(k, 3, ix->d) <= S16_MAX_K) {
                     const int rh = ensure_hi_plane(ix, st);
                     if (rh < 0) return rh;
                     if (rh == 0) mode = 3;
                 }
+                if (mode == 0) goto exact_kernels;
                 // (a small batch gains only from the one-product pass on the hi plane, which the bf16 stream kernel
                 // reads once; without it -- no room for that plane, or a corpus that needs more products -- the exact
                 // stream kernels below are at least as fast as a 256-query-tile scan with 1 ... 32 real columns)
@@ -2966,6 +2978,7 @@ int search_chunk(otter_index* ix, const float* qd, long long nq, int k, float* D
             }
         }
     }
+exact_kernels:
     static const char* no_stream = getenv("OTTER_NO_STREAM");
     // (1 ... 16 queries: 4x4x1 products, 17 ... 32: 32x32x2 blocks, both in the stream structure)
     if (nq <= 32 && k <= 128 && !no_stream) return search_chunk_stream(ix, qd, nq, k, D, I, st, sc);
@@ -3357,10 +3370,25 @@ int ensure_hi_plane(otter_index* ix, hipStream_t st) {
         hipLaunchKernelGGL(to_bf16_rows_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 8192)), dim3(256), 0,
                            st, (const float*)ix->x + (size_t)lo * ix->ld, (unsigned short*)ix->xh.p, rows, rows, ix->ld,
                            ix->ld, lo);
+        // (hi plane only: the row norms the margin proof needs come from here; with the split planes, from their pass)
+        float* nrm = nullptr;
+        if (ix->planes == 1) {
+            if (ix->xnorm2.bytes < (size_t)ix->cap_rows * sizeof(float)) {
+                if ((rc = ix->xnorm2.reserve((size_t)ix->cap_rows * sizeof(float)))) return rc;
+            }
+            if (!ix->xnmax.p) {
+                if ((rc = ix->xnmax.reserve(sizeof(u32)))) return rc;
+                OTTER_HIP_TRY(hipMemsetAsync(ix->xnmax.p, 0, sizeof(u32), st));
+            }
+            nrm = (float*)ix->xnorm2.p + lo;
+        }
         hipLaunchKernelGGL(residual_norm_kernel, dim3((unsigned)std::min<long long>((rows + 3) / 4, 16384)), dim3(256), 0, st,
-                           (const float*)ix->x + (size_t)lo * ix->ld, rows, ix->ld, (float*)ix->xres2.p + lo);
+                           (const float*)ix->x + (size_t)lo * ix->ld, rows, ix->ld, (float*)ix->xres2.p + lo, nrm);
         hipLaunchKernelGGL(max_norm_kernel, dim3((unsigned)std::min<long long>((rows + 255) / 256, 1024)), dim3(256), 0,
                            st, (const float*)ix->xres2.p + lo, rows, (u32*)ix->xrmax.p);
+        if (nrm)
+            hipLaunchKernelGGL(max_norm_kernel, dim3((unsigned)std::min<long long>((rows + 255) / 256, 1024)), dim3(256), 0,
+                               st, (const float*)nrm, rows, (u32*)ix->xnmax.p);
         OTTER_HIP_TRY(hipGetLastError());
         ix->xh_rows = ix->n;
     }
@@ -3502,7 +3530,7 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
     hipLaunchKernelGGL(compact_flags_kernel, dim3(1), dim3(1024), 0, st, (const u32*)flags, nq, (int*)bw.p);
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)nf), dim3(256), 0, st, qd, (const int*)bw.p, (float*)bq.p, ix->d);
     OTTER_HIP_TRY(hipGetLastError());
-    if (mode >= 2 && nf >= 33) {
+    if (mode >= 2 && nf >= 33 && ix->planes == 2) {
         const int next = (mode == 3 && !ix->two_prod_off && split_kc(k, 2, ix->d) <= S16_MAX_K) ? 2 : 1;
         rc = search_chunk_split(ix, (const float*)bq.p, nf, k, (float*)bD.p, (long long*)bI.p, st, next, false);
     } else {
@@ -3870,6 +3898,28 @@ int otter_index_timing(otter_index* ix, double* scan_ms, int64_t* scan_launches)
     *scan_ms = total;
     *scan_launches = (int64_t)ix->ev_pending.size();
     ix->ev_pending.clear();
+    return OTTER_OK;
+}
+
+int otter_index_set_planes(otter_index* ix, int planes) {
+    if (!ix) return set_err(OTTER_EINVAL, "set_planes: index is NULL");
+    if (planes < 0 || planes > 2) return set_err(OTTER_EINVAL, "set_planes: planes=%d outside {0, 1, 2}", planes);
+    DeviceGuard g(ix->device);
+    if (!g.ok) return set_err(OTTER_EHIP, "set_planes: hipSetDevice(%d) failed", ix->device);
+    OTTER_HIP_TRY(hipDeviceSynchronize());      // nothing may still be reading a plane that is freed below
+    if (planes < 2) {
+        ix->xs.release();
+        ix->xnorm2.release();
+        ix->xs_rows = ix->xs_cap = 0;
+        ix->xs_failed = false;
+    }
+    if (planes < 1) {
+        ix->xh.release();
+        ix->xres2.release();
+        ix->xh_rows = ix->xh_cap = 0;
+        ix->xh_failed = false;
+    }
+    ix->planes = planes;
     return OTTER_OK;
 }
 

@@ -40,9 +40,15 @@ class IndexFlatIP:
     device : int       HIP device ordinal
     id_base : int      added to every reported id (row-sharded use: the shard's first global row)
     dtype : str        'fp32' = IndexFlatIP's arithmetic; 'bf16' = rows and queries rounded to bfloat16
+    planes : str       HBM economy of an fp32 index: 'all' (default; 2.5x the corpus' bytes once the first search has
+                       built the bf16 planes of the coarse pass), 'hi' (1.5x: the one-product pass only, what it cannot
+                       prove goes to the exact kernels -- the choice for serving small batches), 'none' (1.0x: exact
+                       kernels only).  Same result bits under every setting (otter_index_set_planes).
     """
 
-    def __init__(self, d, device=0, id_base=0, dtype="fp32"):
+    PLANES = {"none": 0, "hi": 1, "all": 2}
+
+    def __init__(self, d, device=0, id_base=0, dtype="fp32", planes="all"):
         self._lib = _lib.load()
         self.d = int(d)
         self.device = int(device)
@@ -55,6 +61,9 @@ class IndexFlatIP:
         self.id_base = 0
         if id_base:
             self.set_id_base(id_base)
+        self.planes = "all"
+        if planes != "all":
+            self.set_planes(planes)
 
     # -- faiss attributes
     @property
@@ -64,6 +73,13 @@ class IndexFlatIP:
     @property
     def is_trained(self):
         return True
+
+    def set_planes(self, planes):
+        """'none' | 'hi' | 'all': which bf16 planes the index keeps beside its fp32 rows (see the class docstring)."""
+        if planes not in self.PLANES:
+            raise ValueError("planes must be 'none', 'hi' or 'all'")
+        _lib.check(self._lib.otter_index_set_planes(self._h, self.PLANES[planes]), "otter_index_set_planes")
+        self.planes = planes
 
     def set_id_base(self, id_base):
         _lib.check(self._lib.otter_index_set_id_base(self._h, int(id_base)), "otter_index_set_id_base")

@@ -247,3 +247,35 @@ def test_optimistic_threshold_failures_are_searched_again():
     np.testing.assert_array_equal(I1, I0)
     np.testing.assert_array_equal(D1.view(np.uint32), D0.view(np.uint32))
     ix.close()
+
+
+def test_planes_setting_changes_the_footprint_not_the_result():
+    """otter_index_set_planes: 'all' (2.5x the corpus in HBM), 'hi' (1.5x: one-product pass only), 'none' (1.0x: exact
+    kernels only) -- the same result bits for one query, a small and a large batch; switching back and forth frees
+    and rebuilds the planes."""
+    from otter_amd.index import IndexFlatIP
+    g = torch.Generator(device="cuda").manual_seed(21)
+    n, d, k = 300000, 768, 100
+    xb = torch.randn((n, d), generator=g, device="cuda")
+    q = torch.randn((600, d), generator=g, device="cuda")
+    ix = IndexFlatIP(d, planes="none")
+    ix.add(xb)
+    ref = {nq: ix.search(q[:nq].contiguous(), k) for nq in (1, 40, 600)}
+    assert ix.coarse_state == 0                       # no planes were built
+    free_none = torch.cuda.mem_get_info()[0]
+    used = []
+    for planes in ("hi", "all", "hi", "none"):
+        ix.set_planes(planes)
+        for nq, (Dr, Ir) in ref.items():
+            D, I = ix.search(q[:nq].contiguous(), k)
+            assert torch.equal(I, Ir) and torch.equal(D.view(torch.int32), Dr.view(torch.int32)), (planes, nq)
+        torch.cuda.synchronize()
+        used.append(free_none - torch.cuda.mem_get_info()[0])
+    # (the searches' own workspace is in every figure; the planes are what differs)
+    corpus = n * d * 4
+    hi1, all2, hi3, none4 = used
+    assert 0.9 * corpus < all2 - hi3 < 1.1 * corpus, (all2 - hi3) / corpus      # the hi/lo planes: the corpus' bytes again
+    assert 0.45 * corpus < hi3 - none4 < 0.6 * corpus, (hi3 - none4) / corpus   # the hi plane: half of them
+    with pytest.raises(ValueError):
+        ix.set_planes("some")
+    ix.close()
