@@ -528,9 +528,13 @@ struct StreamArgs {
     u64* bmax;           // [4 G][4 * strips] block maxima of every wave's first tile
     u32* sync;           // [0] arrivals, [1] ready (stream16_kernel: number of queries selected), [2..33] thresholds (keys),
                          // [35] next query to select (stream16_kernel); zero at launch, zeroed again by the merge
+    float* hold = nullptr;   // stream64_kernel: [strips][S64_HOLD][16 accumulators][256 lanes] float4, tiles awaiting thresholds
 };
 
-constexpr int ST_BM = 256, ST_SYNC_WORDS = 36;    // [34] unused, [35] claim counter of the distributed selection (stream16_kernel)
+constexpr int ST_BM = 256, ST_SYNC_WORDS = 128;   // [34] unused, [35] claim counter of the distributed selection (stream16_kernel)
+// stream64_kernel: thresholds of up to 64 queries at [2..65], claim counter at [67]; held tiles; LDS image of the queries
+constexpr int S64_CLAIM = 67, S64_HOLD = 3, S64_NQP = 64;
+__host__ __device__ constexpr u32 s64_pitch(int ld) { return (u32)ld * 2u + (((ld / 64) & 1) ? 0u : 128u); }   // odd multiple of 128 B
 constexpr int st_qinstr(int G, int BK) { return (4 * G * BK * 4 + 1023) / 1024; }              // LDS-DMA instructions for the queries
 constexpr int st_slot(int G, int BK) { return 64 * BK * 4 + st_qinstr(G, BK) * 1024; }        // per wave and stage
 constexpr int st_ips(int G, int BK) { return BK / 4 + st_qinstr(G, BK); }                     // LDS-DMA instructions per wave and stage
@@ -1406,6 +1410,303 @@ __global__ __launch_bounds__(256) void stream16_kernel(StreamArgs a) {
             }
         } else if (__builtin_amdgcn_readfirstlane(sFlag[0])) {
             compact_pass(false);
+        }
+    }
+    compact_pass(true);
+    if (tid < NQP) a.cnt[(size_t)strip * NQP + tid] = min(sCnt[tid], (u32)CAP);
+}
+
+// ------------------------------------------------------------------ stream kernel, bf16 storage, 33 ... 64 queries
+// Between 33 and 256 queries the 256-column scan16 tile computes mostly padding (0.41 ms at 33 queries against
+// 0.27 ms at 32).  Up to 64 queries the pass is still one read of the plane: this kernel keeps stream16_kernel's
+// wave-private streaming, k order and candidate path, and changes where the operands live:
+//   queries   ALL slabs of the (at most 64) query rows stay in LDS for the whole launch (64 x (2 ld + 128) bytes:
+//             104 KiB at ld = 768), filled once by LDS-DMA from the query plane with the source-side swizzle; rows
+//             are pitched an odd multiple of 128 bytes so that the 16 rows of one ds_read_b128 group fall on 16
+//             distinct 16-byte bank slots.  Nothing of Q is loaded again, so a stage costs the corpus bytes only.
+//   corpus    from HBM into REGISTERS (eight fully coalesced 1 KiB loads per 8 KiB stage, non-temporal) through a
+//             ring of three register stages -- 16 KiB per wave in flight without any LDS behind it --, and only the
+//             stage being consumed passes through 8 KiB of wave-private LDS to reach MFMA operand layout.  (Loading
+//             operand layout straight from memory -- 16 bytes of 16 different rows per 16 lanes -- ran at 4.2 TB/s.)
+//             The loads are ordinary compiler-visible loads: with no LDS-DMA in the main loop the compiler's own
+//             vmcnt accounting is exact (it waits for the oldest stage with the two younger ones outstanding), and
+//             no register is written behind its back.
+//   held      the tiles scored before the exchanged thresholds arrive wait in a global scratch (64 KiB per tile and
+//             workgroup, written and read back by the same lane), not in registers: 64 accumulators per lane
+//             leave no room for stream16_kernel's register copies.
+// Scores are scan16_kernel<0>'s bit for bit (same operand roles, same k order).
+template <int QG, int EPL>
+__global__ __launch_bounds__(256) void stream64_kernel(StreamArgs a) {
+    constexpr int NQP = 16 * QG;
+    constexpr int G = 4, HOLD = S64_HOLD, CAP = EPL * 64;
+    static_assert(CAP - ST_BM >= 128, "candidate buffer too small");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int KS = a.ld / 64;                  // a.ld = row length in bf16 elements (multiple of 64)
+    const u32 pitch = s64_pitch(a.ld);
+    const u32 qbytes = (u32)NQP * pitch;       // (a multiple of 2048)
+    u32* sCnt = reinterpret_cast<u32*>(smem + qbytes + 4 * 8192);      // (behind the waves' staging buffers)
+    u32* sThr = sCnt + NQP;
+    u32* sFlag = sThr + NQP;      // [0] compaction wanted, [1] thresholds ready, [2] this workgroup selects
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int strip = blockIdx.x;
+    const int t0 = (int)(((long long)strip * a.total_tiles) / a.strips);
+    const int t1 = (int)(((long long)(strip + 1) * a.total_tiles) / a.strips);
+    if (tid < NQP) {
+        sCnt[tid] = 0;
+        sThr[tid] = 0u;            // accept everything (key >= 0) until a threshold is known
+    }
+    if (tid < 3) sFlag[tid] = 0;
+    u64* candBase = a.cand + (size_t)strip * NQP * CAP;
+
+    // ---- the queries: image row r = query r, [KS slabs of 128 B | pad]; chunk position p of a slab holds global
+    // chunk p ^ ((r >> 1) & 7) (consecutive rows alternate between the halves of the 256-byte bank row)
+    {
+        const u32 ppr = pitch >> 4;                 // 16-byte chunks per image row
+        const u32 pieces = qbytes >> 10;
+        const u32 ldsq = (u32)(uintptr_t)(AS3 char*)smem;
+        for (u32 i = (u32)wave; i < pieces; i += 4) {
+            const u32 p = i * 64u + (u32)lane;
+            const u32 row = p / ppr, w = p - row * ppr;
+            u32 ks = w >> 3;
+            const u32 pos = w & 7u;
+            if (ks >= (u32)KS) ks = 0;               // the pad chunks of a row: never read
+            const u32 chunk = pos ^ ((row >> 1) & 7u);
+            dma16s(a.Q, ks * 32768u + row * 128u + chunk * 16u, ldsq + i * 1024u);
+        }
+        wait_vmcnt<0>();
+        wg_barrier();
+    }
+
+    // ---- candidate path.  Lane l holds, per 16-row block g, the scores of rows 16 g + 4 (l >> 4) + i (i = 0..3)
+    // of this wave's 64 for query l & 15 (of column block c)
+    const int rsub = wave * 64 + 4 * (lane >> 4);
+    auto append_tile = [&](const f32x4 (&sc)[QG][G], int tile) {
+#pragma unroll
+        for (int c = 0; c < QG; ++c) {
+            const int q = 16 * c + (lane & 15);
+            const u32 thr = sThr[q];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const long long row0 = (long long)tile * ST_BM + rsub + 16 * g;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u32 key = f2key(sc[c][g][i]);
+                    if (q < a.nq && key >= thr && row0 + i < a.n) {
+                        const u32 pos = atomicAdd(&sCnt[q], 1u);
+                        if (pos < (u32)CAP)
+                            candBase[(u32)q * (u32)CAP + pos] = ((u64)key << 32) | (u64)(0xFFFFFFFFu - (u32)(row0 + i));
+                        if (pos + 1 > (u32)(CAP - ST_BM)) sFlag[0] = 1;
+                    }
+                }
+            }
+        }
+    };
+    auto compact_pass = [&](bool final_pass) {      // workgroup-wide; every wave calls it at the same point
+        wait_vmcnt<0>();
+        wg_barrier();
+        for (int q = wave; q < NQP; q += 4) {
+            const int n = (int)min(sCnt[q], (u32)CAP);
+            const bool need = final_pass ? (n > a.k) : (n > CAP - ST_BM);
+            if (need) {
+                const u64 T = wave_compact<EPL>(candBase + (size_t)q * CAP, n, a.k, lane);
+                if (lane == 0) {
+                    sCnt[q] = (u32)a.k;
+                    sThr[q] = max(sThr[q], (u32)(T >> 32));
+                }
+            }
+        }
+        if (tid == 0) sFlag[0] = 0;
+        wait_vmcnt<0>();
+        wg_barrier();
+    };
+
+    f32x4 acc[QG][G];
+    f32x4* hold = reinterpret_cast<f32x4*>(a.hold) + (size_t)strip * HOLD * (QG * G * 256) + tid;
+    int nheld = 0, held_tile0 = t0;
+    bool have_thr = a.seed == 0;     // no exchange: thresholds are learned locally from the start
+    bool got_global = a.seed == 0;   // the exchanged thresholds have been taken over (or there are none to wait for)
+#pragma unroll
+    for (int c = 0; c < QG; ++c)
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[c][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- end of a tile (workgroup-wide: every wave passes here once per tile)
+    auto tile_end = [&](int tile) {
+        if (have_thr) {
+            append_tile(acc, tile);
+        } else {
+            if (nheld == 0) held_tile0 = tile;
+#pragma unroll
+            for (int c = 0; c < QG; ++c)
+#pragma unroll
+                for (int g = 0; g < G; ++g) hold[(size_t)((nheld * QG + c) * G + g) * 256] = acc[c][g];
+            ++nheld;
+        }
+        if (a.seed && tile == t0) {
+            // publish the best row of this wave's first tile, per query (composites; 0 = no valid row)
+#pragma unroll
+            for (int cg = 0; cg < QG; ++cg) {
+                const int q = 16 * cg + (lane & 15);
+                u64 c = 0ull;
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const long long row0 = (long long)tile * ST_BM + rsub + 16 * g;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u64 v = (q < a.nq && row0 + i < a.n)
+                                          ? (((u64)f2key(acc[cg][g][i]) << 32) | (u64)(0xFFFFFFFFu - (u32)(row0 + i))) : 0ull;
+                        c = v > c ? v : c;
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o >= 16; o >>= 1) {     // over the lanes that hold this query
+                    const u64 v = __shfl_xor(c, o);
+                    c = v > c ? v : c;
+                }
+                if (lane < 16 && q < a.nq)
+                    __hip_atomic_store(a.bmax + (size_t)q * (4 * a.strips) + 4 * strip + wave, c, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+            wait_vmcnt<0>();            // this wave's stores have left (once per launch: the ring drains with them)
+        }
+#pragma unroll
+        for (int c = 0; c < QG; ++c)
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[c][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        wg_barrier();                   // tile boundary: every wave has appended / published
+        // threshold exchange with the selection shared out, as in stream16_kernel (sync words: [0] arrivals,
+        // [1] queries selected, [2 + q] thresholds, [S64_CLAIM] next query to select)
+        if (!got_global) {
+            if (tid == 0) {
+                u32 arr = 0u;
+                if (tile == t0) arr = __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+                else arr = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u32 done = __hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u32 claim = 0xFFFFFFFFu;
+                if (arr == (u32)a.strips && done < (u32)a.nq) {
+                    const u32 c = __hip_atomic_fetch_add(a.sync + S64_CLAIM, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (c < (u32)a.nq) claim = c;
+                }
+                sFlag[2] = claim;
+                sFlag[1] = done >= (u32)a.nq ? 1u : 0u;
+            }
+            wg_barrier();
+            const u32 claim = sFlag[2];
+            if (claim != 0xFFFFFFFFu) {
+                const int M = 4 * a.strips;          // <= 1024 (host)
+                const int q = (int)claim + wave;
+                if (q < a.nq) {
+                    u64 x[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int idx = e * 64 + lane;
+                        x[e] = idx < M ? __hip_atomic_load(a.bmax + (size_t)q * M + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                       : 0ull;
+                    }
+                    int valid = 0;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) valid += __popcll(__ballot(x[e] != 0ull));
+                    const u32 T = valid >= a.k ? wave_kth_key<16>(x, a.k) : 0u;
+                    if (lane == 0)
+                        __hip_atomic_store(a.sync + 2 + q, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                wait_vmcnt<0>();
+                wg_barrier();
+                if (tid == 0)
+                    __hip_atomic_fetch_add(a.sync + 1, (u32)min(4, a.nq - (int)claim), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (sFlag[1] != 0u && tid < a.nq) {
+                const u32 t = __hip_atomic_load(a.sync + 2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sThr[tid] = max(sThr[tid], t);
+            }
+            wg_barrier();
+            const bool ready = sFlag[1] != 0u;
+            got_global = ready;
+            if (!have_thr && (ready || nheld == HOLD || tile + 1 == t1)) {
+                // flush the held tiles through the filter (without thresholds: one tile at a time, compacting)
+                for (int h = 0; h < nheld; ++h) {
+                    f32x4 sc[QG][G];
+#pragma unroll
+                    for (int c = 0; c < QG; ++c)
+#pragma unroll
+                        for (int g = 0; g < G; ++g) sc[c][g] = hold[(size_t)((h * QG + c) * G + g) * 256];
+                    append_tile(sc, held_tile0 + h);
+                    wg_barrier();
+                    if (__builtin_amdgcn_readfirstlane(sFlag[0])) compact_pass(false);
+                }
+                nheld = 0;
+                have_thr = true;
+            } else if (have_thr && __builtin_amdgcn_readfirstlane(sFlag[0])) {
+                compact_pass(false);
+            }
+        } else if (__builtin_amdgcn_readfirstlane(sFlag[0])) {
+            compact_pass(false);
+        }
+    };
+
+    // ---- main loop.  K-slab ks of tile t is the 32 KiB block t KS + ks of the tile-blocked plane; this wave's 64
+    // rows of it are 8 KiB of consecutive bytes.  The ring is three register stages and the loop body is exactly
+    // three steps, so every stage keeps its registers across the back edge (no rotation copies, which would have
+    // to wait for loads in flight); a tile is walked in KSP = 3 ceil(KS / 3) steps, the steps past KS load the
+    // last slab again and skip the products.
+    const u32 fr = (u32)(lane & 15), fq = (u32)(lane >> 4);
+    const char* Xw = reinterpret_cast<const char*>(a.X) + ((u32)wave * 8192u + (u32)lane * 16u);
+    const int KSP = (KS + 2) / 3 * 3;
+    // loads: instruction i reads the 1 KiB of rows 8 i .. 8 i + 7 whole (lane l: row 8 i + (l >> 3), chunk l & 7) --
+    // full 128-byte lines per 8 lanes; MFMA operand layout straight from memory would be 16 lines per 16 lanes
+    auto load_stage = [&](f32x4 (&x)[2 * G], int tile, int ks) {       // (ks may run up to KSP + 1: into the next tile)
+        if (ks >= KSP) { ks -= KSP; ++tile; }
+        tile = min(tile, t1 - 1);
+        ks = min(ks, KS - 1);
+        const char* p = Xw + ((size_t)((u32)tile * (u32)KS + (u32)ks) << 15);
+#pragma unroll
+        for (int i = 0; i < 2 * G; ++i) x[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + i * 1024));
+    };
+    // staging: the stage being consumed goes through this wave's own 8 KiB of LDS to reach operand layout
+    // (row r, chunk c at r * 128 + ((c ^ ((r >> 1) & 7)) << 4): conflict-free both ways); same wave, LDS executes
+    // a wave's instructions in order: no barrier
+    char* sX = smem + qbytes + wave * 8192;
+    const u32 wr0 = (u32)(lane >> 3) * 128u + ((((u32)lane & 7u) ^ ((u32)(lane >> 4) & 7u)) << 4);          // rows 8 i, i even
+    const u32 wr1 = (u32)(lane >> 3) * 128u + ((((u32)lane & 7u) ^ ((4u + (u32)(lane >> 4)) & 7u)) << 4);   // i odd
+    const u32 rswz = (fr >> 1) & 7u;
+    const char* sQl = smem + fr * pitch;
+    const char* sXl = sX + fr * 128u;
+    auto step = [&](const f32x4 (&cur)[2 * G], f32x4 (&nxt)[2 * G], int tile, int ks) {
+        load_stage(nxt, tile, ks + 2);
+        if (ks < KS) {
+#pragma unroll
+            for (int i = 0; i < 2 * G; ++i)
+                *reinterpret_cast<f32x4*>(sX + i * 1024 + ((i & 1) ? wr1 : wr0)) = cur[i];
+            const char* sQ = sQl + ks * 128;
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                const u32 co = ((4u * ks2 + fq) ^ rswz) << 4;
+                f32x4 qf[QG], xf[G];
+#pragma unroll
+                for (int c = 0; c < QG; ++c) qf[c] = *reinterpret_cast<const f32x4*>(sQ + (u32)c * 16u * pitch + co);
+#pragma unroll
+                for (int g = 0; g < G; ++g) xf[g] = *reinterpret_cast<const f32x4*>(sXl + g * 2048 + co);
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int c = 0; c < QG; ++c)
+                        acc[c][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf[g]),
+                                                                            __builtin_bit_cast(bf16x8, qf[c]), acc[c][g], 0, 0, 0);
+            }
+        }
+    };
+    if (t1 > t0) {
+        f32x4 x0[2 * G], x1[2 * G], x2[2 * G];
+        load_stage(x0, t0, 0);
+        load_stage(x1, t0, 1);
+        for (int tile = t0; tile < t1; ++tile) {
+            for (int ks = 0; ks < KSP; ks += 3) {
+                step(x0, x2, tile, ks);
+                step(x1, x0, tile, ks + 1);
+                step(x2, x1, tile, ks + 2);
+            }
+            tile_end(tile);
         }
     }
     compact_pass(true);
@@ -2582,6 +2883,20 @@ void launch_stream16(const StreamArgs& a, int grid, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
 }
 
+template <int QG, int EPL>
+void launch_stream64(const StreamArgs& a, int grid, hipStream_t st) {
+    auto kern = stream64_kernel<QG, EPL>;
+    const int lds = 16 * QG * (int)s64_pitch(a.ld) + (2 * 16 * QG + 4) * (int)sizeof(u32) + 4 * 8192;
+    static int attr_lds[64] = {};        // (the image grows with ld: raise the limit when a longer row comes)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && attr_lds[dev] < lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_lds[dev] = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+}
+
 struct Scan16Cfg {
     int cap;
     void (*launch)(const Scan16Args&, int grid, hipStream_t);
@@ -2691,7 +3006,7 @@ struct otter_index {
                                     // other, e.g. near-duplicate rows): this corpus is searched by the exact kernel from then on
     long long last_stage0_unproven = 0;
     otter::DevBuf qs, qnorm2, cD, cI, rs, rscnt, flags, fb_q, fb_D, fb_I;
-    otter::DevBuf qpad, cand, cnt, lvl[2], lvlcnt[2], smp, smpcnt, thr0, io_q, io_D, io_I, bmax, sync;
+    otter::DevBuf qpad, cand, cnt, lvl[2], lvlcnt[2], smp, smpcnt, thr0, io_q, io_D, io_I, bmax, sync, hold;
     bool sync_dirty = true;         // the stream kernel's counters are not known to be zero
     u32* h_flag = nullptr;          // pinned word for the one read-back of a coarse pass
     bool timing = false;
@@ -2855,15 +3170,24 @@ int ensure_hi_plane(otter_index* ix, hipStream_t st);
 // device-side dirty flags of the static scratch's stream-kernel counters (shared by every index of a GPU)
 bool g_scratch_sync_dirty[64] = {};
 
-// at most 32 queries, k <= 128: the stream kernel + one merge (no sample pass, no pad kernel for aligned rows)
+// 33 ... 64 queries on a bf16 plane: the LDS image of the queries (stream64_kernel) has to fit beside the counters
+bool stream64_fits(const otter_index* ix, long long nq) {
+    static const char* off = getenv("OTTER_NO_STREAM64");
+    return !off && nq > 32 && nq <= S64_NQP && (size_t)S64_NQP * s64_pitch(ix->ld) + 1024 + 4 * 8192 <= 160 * 1024;
+}
+
+// at most 32 queries (64 on a bf16 plane), k <= 128: the stream kernel + one merge (no sample pass, no pad kernel for aligned rows)
 int search_chunk_stream(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st,
                         Scratch* sc, const void* q16_plane = nullptr, const void* x16_plane = nullptr) {
     // x16_plane: a bf16 plane of an OTTER_F32 index (its hi values: the one-product coarse pass of a small batch);
     // k may then be a coarse k + margin of up to 320, which takes the 768-slot candidate lists
     const bool b16 = ix->dtype == OTTER_BF16 || x16_plane != nullptr;   // stream16_kernel: q16_plane = the queries' bf16 plane
     const int EPL = k <= 160 ? 8 : 12, CAP = EPL * 64;
+    const bool wide = nq > 32;                  // 33 ... 64 queries: stream64_kernel (bf16 planes only; see stream64_fits)
+    if (wide && (!b16 || sc->fixed || !stream64_fits(ix, nq)))
+        return set_err(OTTER_EINVAL, "stream search: %lld queries do not fit the stream kernels", nq);
     const int G = nq <= 16 ? (b16 ? 4 : nq <= 4 ? 1 : nq <= 8 ? 2 : 4) : 8;     // query columns / 4
-    const int nqp = 4 * G;
+    const int nqp = wide ? S64_NQP : 4 * G;
     const int total_tiles = (int)((ix->n + ST_BM - 1) / ST_BM);
     int strips = std::min(std::min(ix->ncu, NA_MAX_STRIPS), total_tiles);
     strips = std::max(strips, 1);
@@ -2873,13 +3197,15 @@ int search_chunk_stream(otter_index* ix, const float* qd, long long nq, int k, f
     if (!q_in_place && (rc = sc->get(ix->qpad, (size_t)nqp * ix->ld * sizeof(float), &w_qpad))) return rc;
     if ((rc = sc->get(ix->cand, (size_t)strips * nqp * CAP * sizeof(u64), &w_cand))) return rc;
     if ((rc = sc->get(ix->cnt, (size_t)strips * nqp * sizeof(u32), &w_cnt))) return rc;
-    if ((rc = sc->get(ix->bmax, (size_t)32 * 4 * NA_MAX_STRIPS * sizeof(u64), &w_bmax))) return rc;
+    if ((rc = sc->get(ix->bmax, (size_t)(wide ? S64_NQP : 32) * 4 * NA_MAX_STRIPS * sizeof(u64), &w_bmax))) return rc;
+    void* w_hold = nullptr;
+    if (wide && (rc = sc->get(ix->hold, (size_t)strips * S64_HOLD * (S64_NQP / 16 * 4) * 256 * 16, &w_hold))) return rc;
     const void* sync_before = ix->sync.p;
     if (sc->fixed) w_sync = sc->fixed;          // reserved head of the static scratch (no other layout touches it)
-    else if ((rc = sc->get(ix->sync, 64 * sizeof(u32), &w_sync))) return rc;
+    else if ((rc = sc->get(ix->sync, ST_SYNC_WORDS * sizeof(u32), &w_sync))) return rc;
     bool& dirty = sc->fixed ? g_scratch_sync_dirty[ix->device] : ix->sync_dirty;
     if (!sc->fixed && ix->sync.p != sync_before) dirty = true;       // a fresh allocation is not zero
-    if (dirty) OTTER_HIP_TRY(hipMemsetAsync(w_sync, 0, 64 * sizeof(u32), st));
+    if (dirty) OTTER_HIP_TRY(hipMemsetAsync(w_sync, 0, ST_SYNC_WORDS * sizeof(u32), st));
     dirty = true;                                                     // until this search's merge has been enqueued
     if (!q_in_place) {
         const long long total = (long long)nqp * ix->ld;
@@ -2903,6 +3229,7 @@ int search_chunk_stream(otter_index* ix, const float* qd, long long nq, int k, f
     sa.seed = (!no_seed && 4 * strips >= 2 * k && total_tiles >= 2 * strips) ? 1 : 0;
     sa.bmax = (u64*)w_bmax;
     sa.sync = (u32*)w_sync;
+    sa.hold = (float*)w_hold;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     const bool timed = ix->timing && ix->ev_pending.size() < 4096 && !sc->fixed;
     if (timed) {
@@ -2916,7 +3243,9 @@ int search_chunk_stream(otter_index* ix, const float* qd, long long nq, int k, f
         OTTER_HIP_TRY(hipEventRecord(ev.first, st));
     }
     // (ring depth by LDS: 4 waves x slots x (8 KiB + queries))
-    if (b16 && EPL == 12 && G <= 4) launch_stream16<1, 12, 3>(sa, strips, st);
+    if (wide && EPL == 12) launch_stream64<4, 12>(sa, strips, st);
+    else if (wide) launch_stream64<4, 8>(sa, strips, st);
+    else if (b16 && EPL == 12 && G <= 4) launch_stream16<1, 12, 3>(sa, strips, st);
     else if (b16 && EPL == 12) launch_stream16<2, 12, 3>(sa, strips, st);
     else if (b16 && G <= 4) launch_stream16<1, 8, 3>(sa, strips, st);
     else if (b16) launch_stream16<2, 8, 3>(sa, strips, st);
@@ -3289,7 +3618,7 @@ int search_chunk_bf16(otter_index* ix, const float* qd, long long nq, int k, flo
         OTTER_HIP_TRY(hipGetLastError());
     }
     static const char* no_stream = getenv("OTTER_NO_STREAM");
-    if (nq <= 32 && k <= 128 && !no_stream) {
+    if ((nq <= 32 || stream64_fits(ix, nq)) && k <= 128 && !no_stream) {
         Scratch own;
         return search_chunk_stream(ix, qd, nq, k, D, I, st, &own, ix->qs.p);
     }
@@ -3447,7 +3776,7 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
     bool optimistic = false;
     if (mode == 3) {
         static const char* no_stream16 = getenv("OTTER_NO_STREAM");
-        if (nq <= 32 && kc <= 320 && !no_stream16) {
+        if ((nq <= 32 || stream64_fits(ix, nq)) && kc <= 320 && !no_stream16) {
             // a small batch: the coarse pass is one read of the hi plane by the bf16 stream kernel (half the bytes of
             // the fp32 rows), its kc candidates go through the same re-scoring and proof
             Scratch own;
@@ -3710,7 +4039,7 @@ int otter_index_search_noalloc(otter_index* ix, const float* q, int64_t nq, int 
     Scratch sc;
     sc.fixed = g_scratch_ptr[ix->device];       // resolved by otter_index_create on this device
     sc.fixed_bytes = NA_SCRATCH_BYTES;
-    sc.used = 256;                              // the first 256 bytes hold the stream kernel's counters
+    sc.used = 512;                              // the first 512 bytes hold the stream kernel's counters (ST_SYNC_WORDS)
     if (!sc.fixed) return set_err(OTTER_ESTATE, "search_noalloc: static scratch of device %d was not resolved", ix->device);
     return search_chunk(ix, q, nq, k, D, (long long*)I, st, &sc);
 }
@@ -3953,6 +4282,7 @@ void otter_index_destroy(otter_index* ix) {
     ix->smpcnt.release();
     ix->thr0.release();
     ix->bmax.release();
+    ix->hold.release();
     ix->sync.release();
     ix->io_q.release();
     ix->io_D.release();

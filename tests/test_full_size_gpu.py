@@ -90,7 +90,7 @@ def corpus_1m():
 
 def test_batch_size_ladder_is_one_result(corpus_1m):
     """configs[2]'s query-batch range on one 1M x 768 fp32 shard: whatever regime serves a batch (coarse pass by the
-    bf16 stream kernel up to 32 queries, by the 256-query-tile scan from 33 on, exact re-scoring and proof behind both),
+    bf16 stream kernels up to 64 queries, by the 256-query-tile scan from 65 on, exact re-scoring and proof behind both),
     the rows and scores of a query are the same bits.  Reference = the EXACT fp32 stream kernels (the allocation-free
     entry point, 16 queries per call); independent arbiter = the oracle's float64 rule on a sample."""
     from otter_amd.index import IndexFlatIP
@@ -102,7 +102,7 @@ def test_batch_size_ladder_is_one_result(corpus_1m):
     Ir = torch.empty((4096, K), dtype=torch.int64, device="cuda")
     for lo in range(0, 4096, 16):
         ix.search_noalloc(q[lo:lo + 16].contiguous(), K, Dr[lo:lo + 16], Ir[lo:lo + 16])
-    for nq in (1, 8, 16, 17, 32, 33, 64, 256, 4096):
+    for nq in (1, 8, 16, 17, 32, 33, 48, 64, 65, 96, 192, 256, 4096):
         D, I = ix.search(q[:nq].contiguous(), K)
         assert torch.equal(I, Ir[:nq]), "batch of %d: ids differ from the 16-query calls" % nq
         assert torch.equal(D.view(torch.int32), Dr[:nq].view(torch.int32)), "batch of %d: scores differ" % nq
