@@ -1850,7 +1850,12 @@ __global__ __launch_bounds__(512, 2) void scan16_kernel(Scan16Args a) {
     auto mfma = [&](f32x4& c, const float4& w, const float4& x) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
     };
+    // a batch that ends inside the first 128 queries of this tile leaves group 1 (queries 128 ... 255) with padding
+    // only: its products are skipped -- the barriers are not, the groups stay in step -- and group 0 has the matrix
+    // cores to itself (65 ... 128 queries: the scan goes from 256 columns' time to about 128 columns')
+    const bool idle_group = g == 1 && a.nq - q0 <= 128;
     auto mma = [&](float4 (&X)[4][2], int mq, int nq) {
+        if (idle_group) return;
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
         if (MODE == 0) {
@@ -3782,7 +3787,8 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
             Scratch own;
             rc = search_chunk_stream(ix, qd, nq, kc, (float*)ix->cD.p, (long long*)ix->cI.p, st, &own, ix->qh16.p, ix->xh.p);
         } else {
-            optimistic = nq >= 512;     // (few query tiles: short strips, the sample levels are cheap there)
+            // (measured, 1M x 768, one query tile: 65 queries 0.539 -> 0.507 ms, 256: 0.650 -> 0.616, 384: 1.06 -> 1.00)
+            optimistic = nq > S64_NQP;
             rc = scan16_and_merge<0>(ix, ix->xh.p, ix->ld, nq, kc, (float*)ix->cD.p, (long long*)ix->cI.p, st, ix->qh16.p,
                                      &optimistic);
         }
