@@ -178,6 +178,17 @@ def encode_leg(rank, world, local_rank, dist, steps, warmup, batch, cpu_ref, reh
         return None
     dev_ms = e0.elapsed_time(e1) / steps
     flops_block = layers * (24.0 * L * H * H + 4.0 * L * L * H)
+    # HBM-side bytes per forward from a separate rocprofv3 --pmc pass over tools/bench_encoder.py (same shape, same
+    # batch): a committed constant, labelled as such
+    enc_traffic, enc_traffic_source = None, None
+    tp = os.path.join(ROOT, "profiles", "r03_encode_traffic.json")
+    if os.path.exists(tp) and (batch, L, layers) == (128, 512, 12):
+        with open(tp) as f:
+            tj = json.load(f)
+        enc_traffic = float(tj["encode_hbm_bytes_per_forward"])
+        enc_traffic_source = {"file": "profiles/r03_encode_traffic.json", "measured_at_commit": tj.get("commit"),
+                              "how": "separate rocprofv3 --pmc passes (tools/pmc.sh + tools/encode_traffic_from_pmc.py), "
+                                     "a committed constant, not measured in this run"}
     achieved = flops_block * batch / (dev_ms * 1e-3) / 1e12
     res = {"value": world * batch * steps / elapsed, "unit": "blocks/s", "dtype": "bf16", "batch_per_gpu": batch,
            "seq_len": L, "model": "roberta-base shape, random init", "ms_per_batch": elapsed / steps * 1e3,
@@ -185,7 +196,7 @@ def encode_leg(rank, world, local_rank, dist, steps, warmup, batch, cpu_ref, reh
                        "embeddings (otter_amd.encode_driver.predict), %d distinct host batches" % nb_distinct,
            "finite": bool(torch.isfinite(emb).all().item()),
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
+                        "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": enc_traffic, "traffic_source": enc_traffic_source,
                         "kernel": "whole forward (12 x [qkv gemm, attention, o gemm, ffn1 gemm, ffn2 gemm], LayerNorms folded into the gemm epilogues)",
                         "device_ms_per_batch": dev_ms, "algorithmic_flops_per_block": flops_block}}
     # SURVEY.md §8d ragged variant, reported separately: token counts ~U[64, 512] padded to 512 the way the
@@ -251,6 +262,11 @@ def scan16_dispatches(n, nq, k, d, nprod):
     qtiles, total = -(-nq // 256), -(-n // 256)
     wgs = max(1, ncu // qtiles)
     cover = total // (4 if qtiles >= 8 else 8)
+    if nprod == 1 and nq > 64 and os.environ.get("OTTER_OPT_THR") != "0":
+        # the optimistic start (one small level 0 + the scan of everything else) where the library takes it
+        l0 = min(wgs, 32, int(1.6 * total / kk))
+        if l0 >= 24 and l0 <= total // 8 and l0 * 256 >= 48 and 12 <= kk:
+            return 2
     l0 = max(1, -(-4 * kk // (wgs * 256))) * wgs
     if l0 == wgs:
         l0 = min(wgs, max(-(-4 * kk // 256), 16, min(32, wgs // 2)))
@@ -409,6 +425,8 @@ def main():
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per scan launch from a separate rocprofv3 --pmc pass (profiles/)")
     args = ap.parse_args()
+    args.traffic_source = ({"file": None, "how": "--traffic-bytes on the command line"} if args.traffic_bytes is not None
+                           else None)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -416,11 +434,15 @@ def main():
     if (args.traffic_bytes is None and (args.rows, args.dim, args.nq, args.k) == (1000000, 768, 2214, 100)
             and not os.environ.get("OTTER_NO_SPLIT")):
         # HBM-side bytes per scan launch from the separate rocprofv3 --pmc passes (profiles/)
-        for name in ("r02_traffic_split.json", "r01_traffic_split.json"):
+        for name in ("r03_traffic_split.json", "r02_traffic_split.json", "r01_traffic_split.json"):
             tp = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tp):
                 with open(tp) as f:
-                    args.traffic_bytes = float(json.load(f)["scan_kernel_hbm_bytes_per_launch"])
+                    tj = json.load(f)
+                args.traffic_bytes = float(tj["scan_kernel_hbm_bytes_per_launch"])
+                args.traffic_source = {"file": "profiles/" + name, "measured_at_commit": tj.get("commit"),
+                                       "how": "separate rocprofv3 --pmc passes (tools/pmc.sh + tools/traffic_from_pmc.py), "
+                                              "a committed constant, not measured in this run"}
                 break
 
     rank = int(os.environ.get("RANK", "0"))
@@ -665,6 +687,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
                          "traffic": args.traffic_bytes,
+                         "traffic_source": args.traffic_source,
                          "kernel": kname,
                          "kernel_ms": kern_ms, "launches": int(launches),
                          "kernel_dispatches_per_launch": scan16_dispatches(n, nq, k, d, nprod) if split else 1,

@@ -24,6 +24,8 @@ Differences from the reference, all deliberate:
 import ctypes
 from collections import OrderedDict
 
+import time
+
 import numpy as np
 import torch
 
@@ -343,6 +345,18 @@ class DataParallel:
             r._weights = module._weights            # the same host tensors: no copy until the replica's first call
             self.replicas.append(r)
         self.training = False
+        # debug counter: host time spent enqueueing each replica's share of a call (scatter copy + forward launches),
+        # seconds, and the calls counted.  The GPUs run side by side only while G x (enqueue time per replica) stays
+        # below the device time of one share: enqueue_report() says how far that is.
+        self.enqueue_s = [0.0] * len(self.replicas)
+        self.enqueue_calls = 0
+
+    def enqueue_report(self):
+        """{'per_replica_ms': [...], 'calls': n, 'sum_ms': host ms per call over all replicas}: the host-side cost of one
+        forward() call; compare sum_ms with the device time of one replica's share (14 ms at 128 x 512)."""
+        n = max(1, self.enqueue_calls)
+        per = [1e3 * t / n for t in self.enqueue_s]
+        return {"per_replica_ms": per, "calls": self.enqueue_calls, "sum_ms": sum(per)}
 
     def eval(self):
         for r in self.replicas:
@@ -377,9 +391,12 @@ class DataParallel:
             if hi <= lo:
                 break
             dev = torch.device("cuda", self.device_ids[g])
+            t0 = time.perf_counter()
             sub = {k: (v[lo:hi].to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
             with torch.cuda.device(dev):
                 outs.append(r(sub)["embed"])
+            self.enqueue_s[g] += time.perf_counter() - t0
+        self.enqueue_calls += 1
         home = torch.device("cuda", self.device_ids[0])
         if len(outs) == 1:
             return {"embed": outs[0].to(home)}
