@@ -279,3 +279,33 @@ def test_planes_setting_changes_the_footprint_not_the_result():
     with pytest.raises(ValueError):
         ix.set_planes("some")
     ix.close()
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(70000, 768, 33, 100), (70001, 768, 64, 100), (66000, 832, 50, 10),
+                                        (131072, 128, 64, 1), (80000, 64, 48, 100), (70000, 960, 37, 20),
+                                        (70000, 1024, 40, 100)])
+def test_33_to_64_queries_are_bit_exact(n, d, nq, k):
+    """33 ... 64 queries of an fp32 index: the coarse pass is stream64_kernel's single read of the hi plane (queries
+    resident in LDS; odd and even slab counts, one- and two-slab rows, a row length whose image does not fit and
+    stays with the 256-column scan), exact re-scoring and proof behind it: D and I bit-exact against oracle mode 1."""
+    xb, q = _mk(n, d, nq, seed=n + d + nq + k)
+    D, I, fb = _search(xb, q, k)
+    Dr, Ir = flat_ip.search_c(xb, q, k, mode=flat_ip.MODE_GPU_ORDER)
+    np.testing.assert_array_equal(I, Ir)
+    np.testing.assert_array_equal(D.view(np.uint32), Dr.view(np.uint32))
+    assert fb <= 3
+
+
+def test_bf16_index_gives_one_result_from_16_to_64_queries():
+    """OTTER_BF16 index: the scores ARE the bf16 products, so the three kernels that serve 16, 32 and 64 queries
+    (stream16_kernel, stream64_kernel) and the 256-column scan (65) must agree bit for bit, ties and all."""
+    from otter_amd.index import IndexFlatIP
+    xb, q = _mk(150000, 768, 65, seed=9)
+    ix = IndexFlatIP(768, dtype="bf16")
+    ix.add(xb)
+    D65, I65 = ix.search(q, 100)
+    for nq in (16, 32, 33, 48, 64):
+        D, I = ix.search(q[:nq], 100)
+        np.testing.assert_array_equal(I, I65[:nq])
+        np.testing.assert_array_equal(D.view(np.uint32), D65[:nq].view(np.uint32))
+    ix.close()
