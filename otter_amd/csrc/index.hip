@@ -2330,6 +2330,183 @@ __global__ void margin_check_kernel(const float* Dexact, const float* Dcoarse, c
     if (!ok) atomicAdd(nflag, 1u);
 }
 
+// ---- small batches (at most 64 queries): re-scoring, final selection and proof in ONE launch ----
+// The reference's call pattern is one query per call: behind the 0.24 ms scan, re-scoring (18 us: a chain of 384
+// dependent 64-cycle fp32 MFMAs per candidate group), the merge of its output (9 us), the margin check (5 us), the
+// copy of the proof word (4 us) and a stream synchronisation were four latency-bound launches.  Here:
+//   * grid = queries x parts, a workgroup re-scores 32 candidates: its four waves bring the rows in as 1 KiB K-blocks
+//     (a wave-load = one row's 256 floats, fully coalesced, up to three blocks = 24 loads per lane in flight -- a
+//     whole 768-float row), lay them into LDS rows pitched 1040 bytes, and 32 lanes of wave 0 run the plain fmaf
+//     chain, lane = candidate, in scan_kernel's k order (0,4,1,5,2,6,3,7 per 8: the oracle's chain, bit for bit);
+//   * composites go to global scratch with agent-scope stores; the LAST workgroup of a query (an agent-scope ticket)
+//     reads all kc of them back, orders them by rank counting, writes (D, I), and decides the query's proof
+//     (margin_check_kernel's rule);
+//   * the last query to finish writes the number of unproven queries straight into pinned host memory (system-scope
+//     store), which the host polls: no copy, no stream synchronisation.  All counters are left at zero.
+struct FinishArgs {
+    const float* X;        // [n][ld]
+    const float* Q;        // [nq][ld] (zero padded rows)
+    const long long* Ic;   // [nq][kc] coarse ids (local row + id_base), -1 = none (the tail)
+    const float* Dc;       // [nq][kc] coarse scores
+    float* D;              // [nq][k]
+    long long* I;          // [nq][k]
+    u64* comp;             // [nq][kc] scratch
+    u32* tick;             // [nq] arrivals per query, [nq] queries finished | unproven queries << 16; zero at launch and after
+    u32* flags;            // [nq] 1 = unproven
+    u32* host_word;        // pinned, host-coherent
+    const float* qnorm2;
+    const u32* xnorm2_max;
+    const float* qres2;    // or null
+    const u32* xres2_max;  // or null
+    float rel;
+    long long id_base, n;
+    int ld, kc, k, nq, parts;
+};
+
+constexpr int FIN_ROWS = 32, FIN_KB = 256, FIN_PITCH = FIN_KB * 4 + 16, FIN_STAGES = 3, FIN_MAX_KC = 320;
+
+__global__ __launch_bounds__(256) void finish_small_kernel(FinishArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char fsm[];
+    char* stage = fsm;                                                        // [FIN_STAGES][32 rows][1040 B]
+    float* sQ = reinterpret_cast<float*>(fsm + FIN_STAGES * FIN_ROWS * FIN_PITCH);   // [ld]
+    __shared__ long long sRow[FIN_ROWS];
+    __shared__ u64 sComp[FIN_MAX_KC];
+    __shared__ u32 sLast, sValid;
+    __shared__ float sEk;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = blockIdx.x / a.parts, part = blockIdx.x - q * a.parts;
+    const int c0 = part * FIN_ROWS;
+    if (tid < FIN_ROWS) {
+        const int ci = c0 + tid;
+        const long long id = ci < a.kc ? a.Ic[(size_t)q * a.kc + ci] : -1ll;
+        sRow[tid] = id >= 0 ? id - a.id_base : -1ll;
+    }
+    for (int i = tid; i < a.ld / 4; i += 256)
+        reinterpret_cast<f32x4*>(sQ)[i] = reinterpret_cast<const f32x4*>(a.Q + (size_t)q * a.ld)[i];
+    __syncthreads();
+    const int S = a.ld / FIN_KB + ((a.ld % FIN_KB) ? 1 : 0);     // K-blocks (ld is a multiple of 64: the last may be short)
+    // pass i of a block: wave w brings row 4 i + w (lane l its 16 bytes l); rows without a candidate read row 0
+    const float* src[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const long long r = sRow[4 * i + wave];
+        src[i] = a.X + (size_t)(r >= 0 ? r : 0) * a.ld + lane * 4;
+    }
+    f32x4 buf[FIN_STAGES][8];
+    auto load_block = [&](f32x4 (&x)[8], int b) {
+        const bool in = b * FIN_KB + lane * 4 < a.ld;             // (a short last block: its tail is never read)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            x[i] = in ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src[i] + b * FIN_KB)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    float acc = 0.0f;
+#pragma unroll
+    for (int s = 0; s < FIN_STAGES; ++s)
+        if (s < S) load_block(buf[s], s);
+    for (int g0 = 0; g0 < S; g0 += FIN_STAGES) {
+#pragma unroll
+        for (int s = 0; s < FIN_STAGES; ++s)
+            if (g0 + s < S) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    *reinterpret_cast<f32x4*>(stage + (s * FIN_ROWS + 4 * i + wave) * FIN_PITCH + lane * 16) = buf[s][i];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < FIN_STAGES; ++s)
+            if (g0 + FIN_STAGES + s < S) load_block(buf[s], g0 + FIN_STAGES + s);      // in flight during the chain
+        if (wave == 0 && lane < FIN_ROWS) {
+            for (int s = 0; s < FIN_STAGES && g0 + s < S; ++s) {
+                const char* st = stage + (s * FIN_ROWS + lane) * FIN_PITCH;
+                const float* qb = sQ + (g0 + s) * FIN_KB;
+                const int n8 = min(FIN_KB, a.ld - (g0 + s) * FIN_KB) / 8;
+#pragma unroll 4
+                for (int j = 0; j < n8; ++j) {
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(st + j * 32);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(st + j * 32 + 16);
+                    const f32x4 q0 = *reinterpret_cast<const f32x4*>(qb + j * 8);
+                    const f32x4 q1 = *reinterpret_cast<const f32x4*>(qb + j * 8 + 4);
+                    acc = __builtin_fmaf(x0[0], q0[0], acc);
+                    acc = __builtin_fmaf(x1[0], q1[0], acc);
+                    acc = __builtin_fmaf(x0[1], q0[1], acc);
+                    acc = __builtin_fmaf(x1[1], q1[1], acc);
+                    acc = __builtin_fmaf(x0[2], q0[2], acc);
+                    acc = __builtin_fmaf(x1[2], q1[2], acc);
+                    acc = __builtin_fmaf(x0[3], q0[3], acc);
+                    acc = __builtin_fmaf(x1[3], q1[3], acc);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- publish this part's composites; the last part of the query goes on
+    if (wave == 0) {
+        if (lane < FIN_ROWS && c0 + lane < a.kc) {
+            const long long r = sRow[lane];
+            const u64 c = r >= 0 ? (((u64)f2key(acc) << 32) | (u64)(0xFFFFFFFFu - (u32)r)) : 0ull;
+            __hip_atomic_store(a.comp + (size_t)q * a.kc + c0 + lane, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        wait_vmcnt<0>();                  // this wave's stores have left
+        if (lane == 0) {
+            const u32 t = __hip_atomic_fetch_add(a.tick + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sLast = (t == (u32)a.parts - 1u) ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    if (sLast == 0u) return;
+    for (int t = tid; t < a.kc; t += 256)
+        sComp[t] = __hip_atomic_load(a.comp + (size_t)q * a.kc + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+        sValid = 0u;
+        sEk = -FLT_MAX;
+        __hip_atomic_store(a.tick + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // left at zero for the next call
+    }
+    __syncthreads();
+    const int k = a.k;
+    for (int t = tid; t < a.kc; t += 256) {
+        const u64 v = sComp[t];
+        if (v != 0ull) {
+            int r = 0;
+            for (int j = 0; j < a.kc; ++j) r += sComp[j] > v;       // (composites of distinct rows are distinct)
+            atomicAdd(&sValid, 1u);
+            if (r < k) {
+                const float sc = key2f((u32)(v >> 32));
+                a.D[(size_t)q * k + r] = sc;
+                a.I[(size_t)q * k + r] = a.id_base + (long long)(0xFFFFFFFFu - (u32)v);
+                if (r == k - 1) sEk = sc;
+            }
+        }
+    }
+    __syncthreads();
+    const int nv = (int)sValid;
+    for (int t = nv + tid; t < k; t += 256) {        // fewer candidates than k: padding
+        a.D[(size_t)q * k + t] = -FLT_MAX;
+        a.I[(size_t)q * k + t] = -1ll;
+    }
+    if (tid == 0) {
+        bool ok;
+        if (a.n <= a.kc) {
+            ok = true;
+        } else {
+            const float tc = a.Dc[(size_t)q * a.kc + a.kc - 1];
+            const float ek = sEk;
+            const float xmax = sqrtf(__uint_as_float(*a.xnorm2_max));
+            float eps = a.rel * sqrtf(a.qnorm2[q]) * xmax;
+            if (a.qres2) eps += 1.001f * sqrtf(a.qres2[q]) * xmax;
+            if (a.xres2_max) eps += 1.005f * sqrtf(a.qnorm2[q]) * sqrtf(__uint_as_float(*a.xres2_max));
+            ok = a.Ic[(size_t)q * a.kc + a.kc - 1] >= 0 && ek > tc + eps;
+        }
+        a.flags[q] = ok ? 0u : 1u;
+        // one word counts both: queries finished (low half) and queries left unproven (high half)
+        const u32 old = __hip_atomic_fetch_add(a.tick + a.nq, 1u + (ok ? 0u : 0x10000u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((old & 0xFFFFu) == (u32)a.nq - 1u) {
+            const u32 nf = (old >> 16) + (ok ? 0u : 1u);
+            __hip_atomic_store(a.tick + a.nq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.host_word, nf, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // Unproven queries of a coarse pass: `which` lists them (ascending).  gather: rows of q -> a dense batch;
 // scatter: the dense batch's result rows back to their places in (D, I).
 __global__ void compact_flags_kernel(const u32* __restrict__ flags, long long nq, int* __restrict__ which) {
@@ -3014,6 +3191,8 @@ struct otter_index {
     otter::DevBuf qpad, cand, cnt, lvl[2], lvlcnt[2], smp, smpcnt, thr0, io_q, io_D, io_I, bmax, sync, hold;
     bool sync_dirty = true;         // the stream kernel's counters are not known to be zero
     u32* h_flag = nullptr;          // pinned word for the one read-back of a coarse pass
+    u32* h_poll = nullptr;          // pinned, host-coherent word the small-batch finish kernel stores its count into
+    otter::DevBuf fin;              // that kernel's counters (zero between launches)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
     // otter_sharded_search: this shard's own stream and staging (queries in, candidates out); on shards[0] also
@@ -3778,10 +3957,11 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
                            st, qd, (float*)ix->qpad.p, nq, nq_pad, ix->d, ix->ld);
     }
     OTTER_HIP_TRY(hipGetLastError());
-    bool optimistic = false;
+    bool optimistic = false, small = false;
     if (mode == 3) {
         static const char* no_stream16 = getenv("OTTER_NO_STREAM");
         if ((nq <= 32 || stream64_fits(ix, nq)) && kc <= 320 && !no_stream16) {
+            small = true;
             // a small batch: the coarse pass is one read of the hi plane by the bf16 stream kernel (half the bytes of
             // the fp32 rows), its kc candidates go through the same re-scoring and proof
             Scratch own;
@@ -3797,38 +3977,96 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
     else
         rc = scan16_and_merge<1>(ix, ix->xs.p, 2 * ix->ld, nq, kc, (float*)ix->cD.p, (long long*)ix->cI.p, st);
     if (rc) return rc;
-    RescoreArgs ra;
-    ra.X = ix->x;
-    ra.Q = q_in_place ? qd : (const float*)ix->qpad.p;
-    ra.Ic = (const long long*)ix->cI.p;
-    ra.out = (u64*)ix->rs.p;
-    ra.out_cnt = (u32*)ix->rscnt.p;
-    ra.id_base = ix->id_base;
-    ra.ld = ix->ld;
-    ra.kc = kc;
-    ra.k = k;
-    ra.nq_pad = (int)nq_pad;
-    ra.zero_word = (u32*)ix->flags.p + nq;        // the margin check's count of unproven queries
-    launch_rescore(ra, (unsigned)nq, st);
-    OTTER_HIP_TRY(hipGetLastError());
-    if ((rc = run_merge(ix, (const u64*)ix->rs.p, (const u32*)ix->rscnt.p, k, S2, nq, nq_pad, k, true, D, I, nullptr,
-                        nullptr, nullptr, nullptr, nullptr, st)))
-        return rc;
     u32* flags = (u32*)ix->flags.p;
-    hipLaunchKernelGGL(margin_check_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (const float*)D,
-                       (const float*)ix->cD.p, (const long long*)ix->cI.p, (const float*)ix->qnorm2.p,
-                       (const u32*)ix->xnmax.p, split_rel_eps(ix->d), nq, k, kc, ix->n, flags, flags + nq,
-                       mode >= 2 ? (const float*)ix->qres2.p : (const float*)nullptr,
-                       mode == 3 ? (const u32*)ix->xrmax.p : (const u32*)nullptr,
-                       optimistic ? (const u32*)ix->thr0.p : (const u32*)nullptr);
-    OTTER_HIP_TRY(hipGetLastError());
-    // the one host round trip of this pass (4 bytes): how many queries are left without a proof.  The
-    // stream is synchronised here -- once per pass of a large-batch search (see include/otter_hip.h).
-    // (into pinned memory: a copy to a pageable word goes through a staging buffer and a second wait)
-    if (!ix->h_flag) OTTER_HIP_TRY(hipHostMalloc((void**)&ix->h_flag, 64, hipHostMallocDefault));
-    OTTER_HIP_TRY(hipMemcpyAsync(ix->h_flag, flags + nq, sizeof(u32), hipMemcpyDeviceToHost, st));
-    OTTER_HIP_TRY(hipStreamSynchronize(st));
-    const long long nf = *ix->h_flag;
+    long long nf = 0;
+    // (read per call: the tests compare the two forms)
+    const char* no_fin = getenv("OTTER_NO_FINISH");
+    if (small && kc <= FIN_MAX_KC && (size_t)ix->ld * 4 <= 32768 && !(no_fin && no_fin[0] == '1')) {
+        // small batch: re-scoring, final selection and proof in one launch, the proof word polled from pinned memory
+        const bool fresh = ix->fin.p == nullptr;
+        if ((rc = ix->fin.reserve(128 * sizeof(u32)))) return rc;
+        if (fresh) OTTER_HIP_TRY(hipMemsetAsync(ix->fin.p, 0, 128 * sizeof(u32), st));
+        if (!ix->h_poll) OTTER_HIP_TRY(hipHostMalloc((void**)&ix->h_poll, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        FinishArgs fa;
+        fa.X = ix->x;
+        fa.Q = q_in_place ? qd : (const float*)ix->qpad.p;
+        fa.Ic = (const long long*)ix->cI.p;
+        fa.Dc = (const float*)ix->cD.p;
+        fa.D = D;
+        fa.I = I;
+        fa.comp = (u64*)ix->rs.p;
+        fa.tick = (u32*)ix->fin.p;
+        fa.flags = flags;
+        fa.host_word = ix->h_poll;
+        fa.qnorm2 = (const float*)ix->qnorm2.p;
+        fa.xnorm2_max = (const u32*)ix->xnmax.p;
+        fa.qres2 = (const float*)ix->qres2.p;
+        fa.xres2_max = (const u32*)ix->xrmax.p;
+        fa.rel = split_rel_eps(ix->d);
+        fa.id_base = ix->id_base;
+        fa.n = ix->n;
+        fa.ld = ix->ld;
+        fa.kc = kc;
+        fa.k = k;
+        fa.nq = (int)nq;
+        fa.parts = (kc + FIN_ROWS - 1) / FIN_ROWS;
+        const size_t lds = (size_t)FIN_STAGES * FIN_ROWS * FIN_PITCH + (size_t)ix->ld * 4;
+        static bool attr_set[64] = {};
+        if (ix->device >= 0 && ix->device < 64 && !attr_set[ix->device]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(finish_small_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, FIN_STAGES * FIN_ROWS * FIN_PITCH + 32768);
+            attr_set[ix->device] = true;
+        }
+        volatile u32* hw = ix->h_poll;
+        *hw = 0xFFFFFFFFu;
+        hipLaunchKernelGGL(finish_small_kernel, dim3((unsigned)(nq * fa.parts)), dim3(256), lds, st, fa);
+        OTTER_HIP_TRY(hipGetLastError());
+        // the one host round trip of this pass: the kernel's last workgroup stores the count of unproven queries here
+        // (every 4096 looks the stream is asked whether it has ended: a kernel that died must not hang the caller)
+        for (unsigned spins = 1; *hw == 0xFFFFFFFFu; ++spins) {
+            if ((spins & 4095u) == 0u) {
+                const hipError_t e = hipStreamQuery(st);
+                if (e != hipErrorNotReady) {
+                    if (e != hipSuccess) OTTER_HIP_TRY(e);
+                    if (*hw == 0xFFFFFFFFu) return set_err(OTTER_EHIP, "search: the finish kernel ended without its proof word");
+                }
+            }
+            __builtin_ia32_pause();
+        }
+        nf = *hw;
+    } else {
+        RescoreArgs ra;
+        ra.X = ix->x;
+        ra.Q = q_in_place ? qd : (const float*)ix->qpad.p;
+        ra.Ic = (const long long*)ix->cI.p;
+        ra.out = (u64*)ix->rs.p;
+        ra.out_cnt = (u32*)ix->rscnt.p;
+        ra.id_base = ix->id_base;
+        ra.ld = ix->ld;
+        ra.kc = kc;
+        ra.k = k;
+        ra.nq_pad = (int)nq_pad;
+        ra.zero_word = (u32*)ix->flags.p + nq;        // the margin check's count of unproven queries
+        launch_rescore(ra, (unsigned)nq, st);
+        OTTER_HIP_TRY(hipGetLastError());
+        if ((rc = run_merge(ix, (const u64*)ix->rs.p, (const u32*)ix->rscnt.p, k, S2, nq, nq_pad, k, true, D, I, nullptr,
+                            nullptr, nullptr, nullptr, nullptr, st)))
+            return rc;
+        hipLaunchKernelGGL(margin_check_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (const float*)D,
+                           (const float*)ix->cD.p, (const long long*)ix->cI.p, (const float*)ix->qnorm2.p,
+                           (const u32*)ix->xnmax.p, split_rel_eps(ix->d), nq, k, kc, ix->n, flags, flags + nq,
+                           mode >= 2 ? (const float*)ix->qres2.p : (const float*)nullptr,
+                           mode == 3 ? (const u32*)ix->xrmax.p : (const u32*)nullptr,
+                           optimistic ? (const u32*)ix->thr0.p : (const u32*)nullptr);
+        OTTER_HIP_TRY(hipGetLastError());
+        // the one host round trip of this pass (4 bytes): how many queries are left without a proof.  The
+        // stream is synchronised here -- once per pass of a large-batch search (see include/otter_hip.h).
+        // (into pinned memory: a copy to a pageable word goes through a staging buffer and a second wait)
+        if (!ix->h_flag) OTTER_HIP_TRY(hipHostMalloc((void**)&ix->h_flag, 64, hipHostMallocDefault));
+        OTTER_HIP_TRY(hipMemcpyAsync(ix->h_flag, flags + nq, sizeof(u32), hipMemcpyDeviceToHost, st));
+        OTTER_HIP_TRY(hipStreamSynchronize(st));
+        nf = *ix->h_flag;
+    }
     if (mode >= 2 && first) ix->last_refined += nf;
     // (a verdict on the corpus needs a batch worth the name: one hard query of a one-query call is not one.  Small
     // calls -- the reference issues ONE query per call -- are judged over a running window of 64 queries per pass,
@@ -4294,6 +4532,8 @@ void otter_index_destroy(otter_index* ix) {
     ix->io_D.release();
     ix->io_I.release();
     if (ix->h_flag) (void)hipHostFree(ix->h_flag);
+    if (ix->h_poll) (void)hipHostFree(ix->h_poll);
+    ix->fin.release();
     if (ix->sh_worker) {
         ix->sh_worker->stop();
         delete ix->sh_worker;

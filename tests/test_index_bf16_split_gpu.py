@@ -309,3 +309,34 @@ def test_bf16_index_gives_one_result_from_16_to_64_queries():
         np.testing.assert_array_equal(I, I65[:nq])
         np.testing.assert_array_equal(D.view(np.uint32), D65[:nq].view(np.uint32))
     ix.close()
+
+
+@pytest.mark.parametrize("n,d,k", [(270000, 768, 100), (270000, 832, 20), (100000, 2304, 100), (270000, 768, 1)])
+def test_small_batch_finish_kernel_equals_the_four_launches(n, d, k, monkeypatch):
+    """Small batches finish in one launch (finish_small_kernel: re-scoring by a plain fmaf chain in the exact kernels'
+    k order, rank-count selection, proof, the count of unproven queries polled from pinned memory).  It must give what
+    the four launches it replaces give (OTTER_NO_FINISH=1: MFMA re-scoring, merge, margin check, copy), bit for bit,
+    for row lengths of one, two and three rounds of K-blocks, and what the exact fp32 kernels give."""
+    from otter_amd.index import IndexFlatIP
+    xb, q = _mk(n, d, 64, seed=n + d + k)
+    ix = IndexFlatIP(d)
+    ix.add(xb)
+    ref = IndexFlatIP(d, planes="none")
+    ref.add(xb)
+    for nq in (1, 5, 32, 40, 64):
+        D, I = ix.search(q[:nq], k)
+        monkeypatch.setenv("OTTER_NO_FINISH", "1")
+        D4, I4 = ix.search(q[:nq], k)
+        monkeypatch.delenv("OTTER_NO_FINISH")
+        np.testing.assert_array_equal(I, I4)
+        np.testing.assert_array_equal(D.view(np.uint32), D4.view(np.uint32))
+        De, Ie = [], []
+        for lo in range(0, nq, 16):
+            a, b = ref.search(q[lo:min(nq, lo + 16)], k)
+            De.append(a)
+            Ie.append(b)
+        np.testing.assert_array_equal(I, np.concatenate(Ie))
+        np.testing.assert_array_equal(D.view(np.uint32), np.concatenate(De).view(np.uint32))
+    assert ix.last_fallback == 0
+    ix.close()
+    ref.close()
