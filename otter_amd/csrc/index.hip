@@ -1725,13 +1725,15 @@ struct Scan16Args {
     int tile_begin;     // first tile of this launch (tiles below belong to the sample pass)
     const u32* thr0;    // [nq_pad] initial score-key threshold per query (null: none)
     int skip_final;     // 1: leave the strip's candidates as they are (<= CAP per query); the merge selects
+    u32* bmax = nullptr;   // BMAX instance: [nq_pad][4 * strips] score keys, the best row of every wave's 64 rows per query
+    int tile_stride = 1;   // BMAX instance: strip s scans the one tile s * tile_stride (a sample spread over the corpus)
 };
 
 constexpr int S16_HT = 16384, S16_BUF = 4 * S16_HT;
 constexpr int S16_AF = 0, S16_BF = S16_HT, S16_BS = 2 * S16_HT, S16_AS = 3 * S16_HT;
 constexpr int S16_BM = 256, S16_BQ = 256;
 
-template <int MODE, int EPL>
+template <int MODE, int EPL, bool BMAX = false>
 __global__ __launch_bounds__(512, 2) void scan16_kernel(Scan16Args a) {
     constexpr int CAP = EPL * 64;
     static_assert(CAP - S16_BM >= 128, "candidate buffer too small");
@@ -1755,8 +1757,8 @@ __global__ __launch_bounds__(512, 2) void scan16_kernel(Scan16Args a) {
     const int strip = __builtin_amdgcn_readfirstlane(wg / a.qtiles);           // an XCD's workgroups share corpus strips
     const int qt = wg - strip * a.qtiles;
     const int q0 = qt * S16_BQ;
-    const int t0 = a.tile_begin + (int)(((long long)strip * a.total_tiles) / a.strips);
-    const int t1 = a.tile_begin + (int)(((long long)(strip + 1) * a.total_tiles) / a.strips);
+    const int t0 = BMAX ? strip * a.tile_stride : a.tile_begin + (int)(((long long)strip * a.total_tiles) / a.strips);
+    const int t1 = BMAX ? t0 + 1 : a.tile_begin + (int)(((long long)(strip + 1) * a.total_tiles) / a.strips);
     const int KT = a.ldk >> 6;
     const int total_stages = (t1 - t0) * KT;
 
@@ -1933,6 +1935,29 @@ __global__ __launch_bounds__(512, 2) void scan16_kernel(Scan16Args a) {
             }
         }
     };
+    // BMAX instance (level 0 of the optimistic start): no candidates at all -- per query only the best score among
+    // this wave's 64 rows of the tile goes out, one key per (query, strip, wave column): the sample the optimistic
+    // threshold is guessed from (bmax_thr_kernel).  127 MB of dumped candidates and a 0.14 ms merge per 2214-query
+    // search become 1 MB and a 5 us kernel; the main scan then covers the sample tiles too.
+    auto bmax_epilogue = [&](int tile) {
+        const long long rbase = (long long)tile * S16_BM + 64 * wn + 4 * fq;
+        const int lim = (int)std::min<long long>(a.n - rbase, 1 << 20);
+        const int M = 4 * a.strips;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int ql = 128 * g + fr + 16 * m;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (16 * nb + i < lim) mx = fmaxf(mx, acc[m][nb][i]);
+            u32 key = f2key(mx);
+            key = max(key, (u32)__shfl_xor((int)key, 16));
+            key = max(key, (u32)__shfl_xor((int)key, 32));
+            if (fq == 0 && q0 + ql < a.nq) a.bmax[(size_t)(q0 + ql) * M + 4 * strip + wn] = key;
+        }
+    };
     // (the accumulators are cleared after a possible compaction, not in the epilogue: 128 registers that
     // are dead while the compaction runs)
     auto zero_acc = [&]() {
@@ -2011,10 +2036,10 @@ __global__ __launch_bounds__(512, 2) void scan16_kernel(Scan16Args a) {
             mma(X1, 1, 0);
             if (++c_t == KT) {
                 c_t = 0;
-                if (g == 1) epilogue(c_tile);
+                if (g == 1) { if (BMAX) bmax_epilogue(c_tile); else epilogue(c_tile); }
                 wg_barrier();
                 if (g == 0) {
-                    epilogue(c_tile);
+                    if (BMAX) bmax_epilogue(c_tile); else epilogue(c_tile);
                     wg_barrier();        // group 0 waits for group 1: every wave is past its epilogue
                 }
                 if (__builtin_amdgcn_readfirstlane(*sFlag)) compact_pass(false);   // same barriers for all waves
@@ -3098,6 +3123,33 @@ void launch_scan16(const Scan16Args& a, int grid, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
 }
 
+// level 0 of the optimistic start: block maxima only (see bmax_epilogue)
+void launch_scan16_bmax(const Scan16Args& a, int grid, hipStream_t st) {
+    auto kern = scan16_kernel<0, 8, true>;
+    const int lds = 2 * S16_BUF + (2 * S16_BQ + 4) * (int)sizeof(u32);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+}
+
+// one wave per query: the key of the rank-th best of its M <= 128 block maxima (0 = fewer than rank blocks)
+__global__ __launch_bounds__(64) void bmax_thr_kernel(const u32* __restrict__ bmax, int M, int rank, u32* __restrict__ thr) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    u64 x[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int i = e * 64 + lane;
+        x[e] = i < M ? ((u64)bmax[(size_t)q * M + i] << 32) | 1ull : 0ull;
+    }
+    const u32 T = M >= rank ? wave_kth_key<2>(x, rank) : 0u;
+    if (lane == 0) thr[q] = T;
+}
+
 // largest k the bf16-MFMA scan keeps per query (its compaction holds CAP / 64 composites per lane)
 constexpr int S16_MAX_K = 1280;   // (1280: top-1000 of an fp32 index plus its coarse-pass margin of k/8)
 
@@ -3188,7 +3240,7 @@ struct otter_index {
                                     // other, e.g. near-duplicate rows): this corpus is searched by the exact kernel from then on
     long long last_stage0_unproven = 0;
     otter::DevBuf qs, qnorm2, cD, cI, rs, rscnt, flags, fb_q, fb_D, fb_I;
-    otter::DevBuf qpad, cand, cnt, lvl[2], lvlcnt[2], smp, smpcnt, thr0, io_q, io_D, io_I, bmax, sync, hold;
+    otter::DevBuf qpad, cand, cnt, lvl[2], lvlcnt[2], smp, smpcnt, thr0, io_q, io_D, io_I, bmax, sync, hold, bmax16;
     bool sync_dirty = true;         // the stream kernel's counters are not known to be zero
     u32* h_flag = nullptr;          // pinned word for the one read-back of a coarse pass
     u32* h_poll = nullptr;          // pinned, host-coherent word the small-batch finish kernel stores its count into
@@ -3664,7 +3716,7 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
     int lv_tiles[8], nlv = 0, sample_tiles = 0;
     const char* opt_env = getenv("OTTER_OPT_THR");                  // 0: off; r: rank of the optimistic threshold (read per call:
     const char* opt_l0_env = getenv("OTTER_OPT_L0");                // tests force failures with r = 1); tiles of its level 0
-    int opt_rank = 0;
+    int opt_rank = 0, opt_l0 = 0;
     if (optimistic && *optimistic && !no_sample && !(opt_env && atoi(opt_env) == 0)) {
         // rows above the r-th best of n0 sample rows: about r N / n0 in the whole corpus, i.e. Gamma(r) N / n0 with the
         // sample's fluctuation; asked for: >= kk, with a failure probability per query far below 1 / nq.  r = 12 and
@@ -3681,8 +3733,7 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
         // 4096 queries -- 16 workgroups per query tile, a 4096-row sample, three times the survivors -- 6.44 -> 6.66:
         // below 24 sample tiles the levels stay)
         if ((l0 >= 24 || opt_l0_env) && l0 <= total_tiles / 8 && (long long)l0 * S16_BM >= 4ll * opt_rank && opt_rank <= kk) {
-            lv_tiles[nlv++] = l0;
-            sample_tiles = l0;
+            opt_l0 = l0;        // (no level: block maxima of l0 tiles spread over the corpus, then ONE scan of every tile)
         } else {
             opt_rank = 0;
         }
@@ -3728,6 +3779,10 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
         if ((rc = ix->smpcnt.reserve((size_t)nq_pad * sizeof(u32)))) return rc;
         if ((rc = ix->thr0.reserve((size_t)nq_pad * sizeof(u32)))) return rc;
     }
+    if (opt_l0) {
+        if ((rc = ix->bmax16.reserve((size_t)nq_pad * 4 * opt_l0 * sizeof(u32)))) return rc;
+        if ((rc = ix->thr0.reserve((size_t)nq_pad * sizeof(u32)))) return rc;
+    }
     Scan16Args sa;
     sa.X = (const char*)Xk;
     sa.Q = Qk ? (const char*)Qk : (const char*)ix->qs.p;
@@ -3750,6 +3805,23 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
             OTTER_HIP_TRY(hipEventCreate(&ev.second));
         }
         OTTER_HIP_TRY(hipEventRecord(ev.first, st));
+    }
+    if (opt_l0) {
+        // the optimistic threshold: rank-th best of the block maxima of opt_l0 tiles (4 blocks of 64 rows each).  At
+        // least `rank` sample rows reach it, so the Gamma(rank) bound above holds for it as for the rank-th best row.
+        sa.strips = opt_l0;
+        sa.total_tiles = opt_l0;
+        sa.tile_begin = 0;
+        sa.tile_stride = total_tiles / opt_l0;
+        sa.thr0 = nullptr;
+        sa.skip_final = 1;
+        sa.bmax = (u32*)ix->bmax16.p;
+        launch_scan16_bmax(sa, qtiles * opt_l0, st);
+        hipLaunchKernelGGL(bmax_thr_kernel, dim3((unsigned)nq), dim3(64), 0, st, (const u32*)ix->bmax16.p, 4 * opt_l0, opt_rank,
+                           (u32*)ix->thr0.p);
+        OTTER_HIP_TRY(hipGetLastError());
+        sa.bmax = nullptr;
+        sa.tile_stride = 1;
     }
     int done_tiles = 0;
     for (int lv = 0; lv < nlv; ++lv) {
@@ -3778,7 +3850,7 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
     sa.strips = strips;
     sa.total_tiles = main_tiles;
     sa.tile_begin = sample_tiles;
-    sa.thr0 = sample ? (const u32*)ix->thr0.p : nullptr;
+    sa.thr0 = (sample || opt_l0) ? (const u32*)ix->thr0.p : nullptr;
     cfg.launch(sa, qtiles * strips, st);
     OTTER_HIP_TRY(hipGetLastError());
     if (timed) {
@@ -4527,6 +4599,7 @@ void otter_index_destroy(otter_index* ix) {
     ix->thr0.release();
     ix->bmax.release();
     ix->hold.release();
+    ix->bmax16.release();
     ix->sync.release();
     ix->io_q.release();
     ix->io_D.release();
