@@ -3725,13 +3725,12 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
         // times a tile's steady-state cost: measured slower) -- so n0 <= 8192 rows, and the optimistic start applies
         // while kk <= 1.6 N / n0 (k = 100 on a million rows: kk = 211, n0 = 7168 at 2214 queries; not k = 1000).
         opt_rank = opt_env ? std::max(1, atoi(opt_env)) : 12;
-        int l0 = std::min(wgs, 32);
+        int l0 = 32;            // (block maxima need no workgroup per strip of the main scan: any number of tiles)
         if (opt_l0_env) l0 = std::max(1, atoi(opt_l0_env));
         const int l0_safe = (int)(1.6 * total_tiles / kk);
         if (!opt_l0_env) l0 = std::min(l0, l0_safe);
-        // (measured, 1M x 768, k = 100, same box: 512 queries 1.02 -> 0.955 ms, 1024: 1.80 -> 1.71, 2214: 3.79 -> 3.68;
-        // 4096 queries -- 16 workgroups per query tile, a 4096-row sample, three times the survivors -- 6.44 -> 6.66:
-        // below 24 sample tiles the levels stay)
+        // (measured, 1M x 768, k = 100, same box, against the sample levels: 512 queries 1.02 -> 0.91 ms, 1024: 1.80 -> 1.62,
+        // 2214: 3.79 -> 3.60, 4096: 6.59 -> 6.27; below 24 sample tiles -- small corpora, large k -- the levels stay)
         if ((l0 >= 24 || opt_l0_env) && l0 <= total_tiles / 8 && (long long)l0 * S16_BM >= 4ll * opt_rank && opt_rank <= kk) {
             opt_l0 = l0;        // (no level: block maxima of l0 tiles spread over the corpus, then ONE scan of every tile)
         } else {
