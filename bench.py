@@ -372,6 +372,8 @@ def count_gpus_sysfs():
     """GPUs of this machine from the kfd topology (nodes with SIMDs; CPU nodes have simd_count 0), WITHOUT any HIP or
     torch.cuda call: the process that spawns the ranks must never have touched the GPU.  None if unreadable."""
     import glob
+    if not os.path.isdir("/sys/class/kfd"):
+        return 0                       # no amdgpu compute driver on this machine: no GPU
     nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
     if not nodes:
         return None
@@ -656,9 +658,11 @@ def main():
                          {1: 0, 2: 2, 3: 1}[nprod],
                          {1: "x_hi*q_hi", 2: "x_hi*q_hi + x_lo*q_hi", 3: "x_hi*q_hi + x_hi*q_lo + x_lo*q_hi"}[nprod]) +
                      "kernel_ms is one HIP-event bracket per search on the launch stream = %d dispatches of this kernel "
-                     "(threshold-seeding sample levels over the first 1/4 of the tiles, each started from the threshold "
-                     "of the levels before it, then the main scan) and the merges between them: rocprof's "
-                     "TotalDurationNs of scan16_kernel / steps + those merges" % scan16_dispatches(n, nq, k, d, nprod))
+                     "and what runs between them: with the optimistic start (2 dispatches) a block-maxima launch over ~29 "
+                     "sample tiles, the 5 us threshold kernel and ONE scan of every tile (sample tiles scored twice: "
+                     "+0.7%% kernel flops, not counted); otherwise threshold-seeding sample levels, the merges between "
+                     "them and the main scan.  rocprof: TotalDurationNs of scan16_kernel / steps + those kernels"
+                     % scan16_dispatches(n, nq, k, d, nprod))
         else:
             kernel_flops, peak = flops, PEAK_FP32_MFMA_TFLOPS
             kname = "scan_kernel (fp32 v_mfma_f32_32x32x2_f32 + fused top-k filter)"

@@ -23,8 +23,11 @@
  *     Calls with device buffers enqueue their work on the stream and return, with
  *     these exceptions, which also wait for it: otter_index_search on an
  *     OTTER_F32 index of 65,536 and more rows whose coarse-pass planes fit HBM
- *     (one 4-byte read-back per pass of the coarse search: how many queries still
- *     lack a proof; usually one pass), otter_index_search_subset (validation of
+ *     (one 4-byte word per pass of the coarse search: how many queries still
+ *     lack a proof; usually one pass.  Above 64 queries it is read back behind a
+ *     stream synchronisation; up to 64 the last kernel of the call stores it into
+ *     pinned memory and the host polls it -- the call returns when the results
+ *     are decided, the kernel's tail may still be retiring on the stream), otter_index_search_subset (validation of
  *     the id lists), otter_index_add when the allocation grows, and
  *     otter_index_timing.  otter_index_search_noalloc, searches of an OTTER_BF16
  *     index and searches of smaller fp32 indexes only enqueue.

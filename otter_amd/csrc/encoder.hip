@@ -646,35 +646,43 @@ __global__ __launch_bounds__(1024 / QB, QB == 2 ? 2 : 4) void attn_full_kernel(A
     }
 }
 
-// ------------------------------------------------------------------ attention, bf16, software-pipelined
-// One 256-thread workgroup per (batch, head), ONE wave per SIMD with the whole 512-register file; all K and V of
-// the head resident in LDS as in attn_full_kernel (same image, same fill, same store).  A wave owns four 32-query
-// blocks, interleaved over the waves (wave w: blocks w, w + 4, w + 8, w + 12, so that short sequences load every
-// SIMD alike).  The unit of work is one 32-query block against one 64-key tile; units are walked tile-major
-// (u = 4 t + block) and the steps of a unit are spread over three consecutive stages, so that ONE stage (one basic
-// block, 16 slots of one MFMA + a slice of vector work each, hand-ordered and pinned with sched_barrier) holds
-//     the score products of unit u + 1          (8 MFMAs, 8 K fragment reads; accumulators start from the key bias)
+// ------------------------------------------------------------------ attention, bf16, software-pipelined, persistent
+// 512 threads = 8 waves, two per SIMD, 256 arch VGPRs each and NO accumulator file (with any AGPR use a 512-thread
+// kernel gets a fixed 128 / 128 split, which spills); min(B * heads, CUs) workgroups, each walking (batch, head) items
+// blockIdx, blockIdx + grid, ...  All K and V of an item's head are resident in LDS (64 KiB + 64 KiB + key bias),
+// same image, fill pieces and store as attn_full_kernel.  Wave w owns the 32-query blocks w and w + 8.
+// The unit of work is one 32-query block against one 64-key tile; the steps of a unit are spread over three
+// consecutive stages, so that ONE stage (one basic block, 16 slots of one MFMA + a slice of vector work each,
+// hand-ordered and pinned with sched_barrier) holds
+//     the score products of unit u + 1          (8 MFMAs, 8 K fragment reads)
 //     the context products of unit u - 1        (8 MFMAs, 16 transposed V reads)
 //     exponentials, row sums, bf16 packing of u (vector ALU)
-// i.e. the matrix pipe and the vector ALU always have independent work from the same instruction stream, and the
-// loop has no branch but its own.
+// i.e. the matrix pipe and the vector ALU always have independent work from the same instruction stream; the second
+// wave of the SIMD fills what issue slots are left (one wave per SIMD with the whole 512-register file was
+// issue-bound: its MFMA and vector parts simply added up).
 // Per score the vector ALU does one v_exp, one add and half a packed convert; nothing else:
 //   * the scale: the query rows arrive pre-multiplied by (1/8) log2(e) -- folded into W_q / b_q at finalize;
-//   * the key-padding bias is the INITIAL VALUE of the score accumulators (read from LDS straight into them);
+//   * the key-padding bias is the INITIAL VALUE of the score accumulators on tiles that hold a masked key (one ballot
+//     over the tile's 64 bias words per item), the MFMA's constant 0 elsewhere;
 //   * no running maximum: softmax is invariant under a per-row factor -- p = 2^s and the row sum carry the same
 //     one -- and fp32 / bf16 hold 2^-126 .. 2^127, while scores of a trained encoder are a few tens at most.
 //     Instead of watching the maximum, the RESULT is checked: a block of queries is accepted iff every row sum
 //     lies in (1e-30, 1e30) (then no exponential overflowed, no context sum can have, and nothing underflowed);
-//     otherwise -- scores beyond +-100, or rows with every key masked -- the wave recomputes that block with a
-//     plain online-softmax loop (attn_block_safe below; slow, exact, never taken on sane inputs).
-// The score products are written as asm: hipcc selects ONE register class for the accumulators of every MFMA builtin
-// of a kernel, and in a 512-register kernel that is the accumulator file -- right for the context accumulators (only
-// MFMAs touch them), wrong for the scores, which the vector ALU reads: every score would be copied out with
-// v_accvgpr_read.  Here: D = C in arch VGPRs, A (keys) in arch VGPRs, B (queries) in the accumulator file.
-// hipcc pads no hazard of an asm statement.  In front: C comes from an LDS read or the previous product of the
-// chain, A from an LDS read, B was written at kernel entry: nothing to pad.  Behind: this MFMA's D must not be read
-// by the vector ALU for 12 wait states (8-pass MFMA); in the pipelined loop the first reader is a whole stage away
-// (order pinned by sched_barrier), elsewhere scores_ready() stands between.
+//     otherwise -- scores beyond +-100, or rows with every key masked -- the block is flagged (a.flags, one byte per
+//     block) and the launch that follows, attn_kernel<bf16> with the flags as its work list, recomputes it with the
+//     plain online-softmax loop (5 us when nothing is flagged; never more on sane inputs).
+// Fill and compute overlap ACROSS items: while item i is computed, the tiles of item i + grid stream by LDS-DMA into
+// the slots item i has finished with (tile t - 2 is refilled in iteration t, the last two after the item's barrier),
+// so a workgroup waits for a fill only at its first item.  Without that every CU filled (65 us per layer in all) and
+// computed in phase with all others.
+// Loads: K/V/bias are LDS-DMA (invisible to hipcc, ordered by hand: vmcnt(0) + barrier once per item); the query rows
+// are PLAIN loads -- hipcc's own wait for them can only be stronger than needed, never weaker, whatever the register
+// allocator does (round 2 hid them in asm and once read a register before it had landed).
+// Two hazards met on the way, both invisible to hipcc: an asm v_add directly behind the v_exp whose result it reads
+// (a transcendental's result needs a wait state: wrong row sums) -- the sums are plain C++ now, one chain of adds and
+// one of fmas by an opaque 1.0 so that they are not packed into v_pk_add --; and per-lane constants computed at kernel
+// entry, which were spilled and reloaded inside the tile loop behind an s_waitcnt vmcnt(0) that drains the refill DMA
+// -- they are derived from the lane id (asm volatile v_mbcnt) where they are used.
 __device__ __forceinline__ void mfma_qk(f32x16& acc, const f32x4v& k, const f32x4v& q) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k), __builtin_bit_cast(bf16x8, q), acc, 0, 0, 0);
 }
@@ -826,7 +834,7 @@ __global__ __launch_bounds__(512, 2) void attn_pipe_kernel(AttnArgs a) {
     // product k / 2, odd = context product k / 2; the LDS reads of a slot are issued PF slots ahead.  `mk`: tile
     // t_qk holds a masked key -- then the score accumulators start from the key bias (read from LDS straight into
     // them), else from the MFMA's constant 0.
-    // The scores read here were written by the asm MFMAs of the previous stage: its chain of keys 0 .. 31 ended in
+    // The scores read here were written by the MFMAs of the previous stage: its chain of keys 0 .. 31 ended in
     // slot 6 there, and the chain of keys 32 .. 63 (slot 14) is first read in slot 4 here -- far beyond the 12 wait
     // states an MFMA result needs before the vector ALU may read it.
     auto stage = [&](int t_qk, bool mk, const f32x4v (&qn)[4], f32x16 (&sn)[2], int t_pv, const bf16x8 (&pprev)[4],
