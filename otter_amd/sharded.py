@@ -208,8 +208,16 @@ class ShardedIndexFlatIP:
         self.last_exchange_bytes = send.nbytes
         Dg, Ig = send.views(recv.view(G, send.nbytes))
         if send.id_bytes == 4:
-            Ig = to_global_ids(Ig, self.bases)
+            Ig = to_global_ids(Ig, self._bases_on(Ig.device))
         return self._merged(Dg, Ig)
+
+    def _bases_on(self, device):
+        """The shards' first ids as a tensor on `device`, copied there once (not per search)."""
+        cache = getattr(self, "_bases_cache", None)
+        if cache is None or cache[0] is not self.bases or cache[1].device != device:
+            cache = (self.bases, self.bases.to(device))
+            self._bases_cache = cache
+        return cache[1]
 
     def _merged(self, Dg, Ig):
         dev = Dg.device
@@ -246,7 +254,7 @@ class ShardedIndexFlatIP:
         dist.all_to_all_single(recv.view(-1), send.buf.view(-1), group=self.group)
         Dr, Ir = send.views(recv)                              # [G, per, kk]: every shard's list of MY queries
         if id_bytes == 4:
-            Ir = to_global_ids(Ir, self.bases)
+            Ir = to_global_ids(Ir, self._bases_on(Ir.device))
         Dm, Im = self._merged(Dr, Ir)
         mine = PackedCandidates(per, kk, D.device)
         Dv, Iv = mine.views()
