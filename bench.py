@@ -316,7 +316,9 @@ def small_batch_leg(index, q, k, n, d):
     default path reads HALF of that -- its coarse pass streams the bf16 hi plane -- and re-scores k + margin rows
     exactly; the exact fp32 stream kernels (the allocation-free entry point) read all of it: both are timed."""
     out = []
-    for nq in (1, 8, 16, 32):
+    for nq in (1, 8, 16, 32, 33, 64, 128, 256):
+        if nq > q.shape[0]:
+            break
         qq = q[:nq].contiguous()
         scan_ms, wall_ms = timed_search(index, qq, k, 30, 5)
         byts = float(n) * d * 4
@@ -329,7 +331,16 @@ def small_batch_leg(index, q, k, n, d):
               # are never read) -- a rate, not a roofline fraction
               "fp32_equivalent_GBps_scan": byts / (scan_ms * 1e-3) / 1e9,
               "fp32_equivalent_GBps_wall": byts / (wall_ms * 1e-3) / 1e9}
-        if k <= 128 and d <= 4096:
+        if k <= 128 and d <= 4096 and nq > 32:
+            # above the allocation-free entry point's 32 queries: compared only, in calls of 32
+            De = torch.empty((nq, k), dtype=torch.float32, device=qq.device)
+            Ie = torch.empty((nq, k), dtype=torch.int64, device=qq.device)
+            for lo in range(0, nq, 32):
+                index.search_noalloc(qq[lo:lo + 32].contiguous(), k, De[lo:lo + 32], Ie[lo:lo + 32])
+            Dd, Id = index.search(qq, k)
+            pt["exact_fp32_kernels"] = {"bit_equal_to_default_path": bool(torch.equal(Id, Ie) and torch.equal(
+                Dd.view(torch.int32), De.view(torch.int32)))}
+        elif k <= 128 and d <= 4096:
             De = torch.empty((nq, k), dtype=torch.float32, device=qq.device)
             Ie = torch.empty((nq, k), dtype=torch.int64, device=qq.device)
             for _ in range(5):
@@ -347,14 +358,17 @@ def small_batch_leg(index, q, k, n, d):
         out.append(pt)
     return {"bound": "hbm", "peak_GBps": PEAK_HBM_GBS, "algorithmic_bytes_per_search": float(n) * d * 4,
             "bytes_read_per_search_default_path": float(n) * d * 2,
-            "kernel": "default path: coarse pass = stream16_kernel over the bf16 hi plane of the fp32 corpus (N*d*2 bytes "
-                      "read once, v_mfma_f32_16x16x32_bf16, in-kernel threshold exchange) + merge + exact fp32 re-scoring of "
-                      "the k + margin candidates + per-query proof: results are the exact fp32 kernels', bit for bit.  "
+            "kernel": "default path: coarse pass over the bf16 hi plane of the fp32 corpus (N*d*2 bytes read once, "
+                      "v_mfma_f32_16x16x32_bf16): stream16_kernel up to 32 queries, stream64_kernel (queries resident in LDS, "
+                      "corpus through a register ring) for 33 ... 64, in-kernel threshold exchange in both; scan16_kernel "
+                      "(256-column tiles, optimistic threshold from block maxima) from 65 on; + merge + exact fp32 re-scoring "
+                      "of the k + margin candidates + per-query proof (up to 64 queries: one launch, finish_small_kernel, "
+                      "its proof word polled from pinned memory): results are the exact fp32 kernels', bit for bit.  "
                       "exact_fp32_kernels (otter_index_search_noalloc): stream_kernel (<= 16 queries: lane = row, per-wave "
                       "LDS-DMA rings with non-temporal loads, v_mfma_f32_4x4x1 fma chain) / stream32_kernel (17 ... 32 "
                       "queries: v_mfma_f32_32x32x2 blocks) + one merge_kernel launch, N*d*4 bytes read once",
-            "note": "scan_ms = HIP events around the kernel that reads corpus rows; wall_ms = host clock per search() call "
-                    "incl. every side kernel, the 4-byte read-back of the proof and the launch gaps; hbm_frac_* price the "
+            "note": "scan_ms = HIP events around the kernel(s) that read corpus rows; wall_ms = host clock per search() call "
+                    "incl. every side kernel, the proof word and the launch gaps; hbm_frac_* price the "
                     "bytes the scan REALLY reads (N*d*2 on the default path, N*d*4 for exact_fp32_kernels) against 8 TB/s; "
                     "fp32_equivalent_GBps_* = the algorithmic N*d*4 bytes per second, a rate that may exceed the HBM peak",
             "points": out}
