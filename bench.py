@@ -152,7 +152,10 @@ def encode_leg(rank, world, local_rank, dist, steps, warmup, batch, cpu_ref, reh
     b = {k: v.cuda() for k, v in hbs[0].items()}
     for _ in range(warmup):
         out = model(b)["embed"]
-    predict(model, hbs[:2])        # pipeline warm-up (pinned staging buffers, copy stream)
+    # pipeline warm-up: pinned staging buffers, copy streams, and one pass of the timed length -- the first predict()
+    # of a given length was measured 11 ms (= 0.5 ms per batch of 20) slower than every later one
+    # (tools/exp_predict_gap.py: 13.94, 13.46, 13.39 ms per batch on three calls in a row)
+    predict(model, [hbs[i % nb_distinct] for i in range(steps)])
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
