@@ -526,12 +526,13 @@ struct StreamArgs {
     int q_rows;          // rows that exist behind Q
     int seed;            // 1: threshold exchange on
     u64* bmax;           // [4 G][4 * strips] block maxima of every wave's first tile
-    u32* sync;           // [0] arrivals, [1] ready (stream16_kernel: number of queries selected), [2..33] thresholds (keys),
-                         // [35] next query to select (stream16_kernel); zero at launch, zeroed again by the merge
+    u32* sync;           // [0] arrivals, [1] ready (stream16 / stream64: number of queries selected), [2..33] thresholds (keys;
+                         // stream64_kernel: [2..65]), [35] next query to select (stream16_kernel; stream64_kernel: [67]);
+                         // ST_SYNC_WORDS words, zero at launch, zeroed again by the merge
     float* hold = nullptr;   // stream64_kernel: [strips][S64_HOLD][16 accumulators][256 lanes] float4, tiles awaiting thresholds
 };
 
-constexpr int ST_BM = 256, ST_SYNC_WORDS = 128;   // [34] unused, [35] claim counter of the distributed selection (stream16_kernel)
+constexpr int ST_BM = 256, ST_SYNC_WORDS = 128;   // (see StreamArgs::sync)
 // stream64_kernel: thresholds of up to 64 queries at [2..65], claim counter at [67]; held tiles; LDS image of the queries
 constexpr int S64_CLAIM = 67, S64_HOLD = 3, S64_NQP = 64;
 __host__ __device__ constexpr u32 s64_pitch(int ld) { return (u32)ld * 2u + (((ld / 64) & 1) ? 0u : 128u); }   // odd multiple of 128 B
@@ -3255,7 +3256,7 @@ struct otter_index {
 };
 
 // Scratch of otter_index_search_noalloc (include/otter_hip.h): one fixed region per GPU, part of the code
-// object, so the entry point never allocates.  Layout = 256 bytes for the stream kernel's counters, then the bump
+// object, so the entry point never allocates.  Layout = 512 bytes for the stream kernel's counters, then the bump
 // allocation order of search_chunk_stream() for the largest shape that entry point accepts (32 queries, k <= 128,
 // d <= 4096, 256 strips):  qpad 32 x 4096 x 4 | cand 256 x 32 x 512 x 8 | cnt | block maxima 32 x 1024 x 8
 constexpr int NA_MAX_NQ = 32, NA_MAX_K = 128, NA_MAX_LD = 4096, NA_MAX_STRIPS = 256;
