@@ -267,7 +267,9 @@ def scan16_dispatches(n, nq, k, d, nprod):
     cover = total // (4 if qtiles >= 8 else 8)
     if nprod == 1 and nq > 64 and os.environ.get("OTTER_OPT_THR") != "0":
         # the optimistic start (one small level 0 + the scan of everything else) where the library takes it
-        l0 = min(wgs, 32, int(1.6 * total / kk))
+        l0 = min(32, int(1.6 * total / kk))
+        if wgs >= 24:
+            l0 = min(l0, wgs)
         if l0 >= 24 and l0 <= total // 8 and l0 * 256 >= 48 and 12 <= kk:
             return 2
     l0 = max(1, -(-4 * kk // (wgs * 256))) * wgs

@@ -3730,6 +3730,9 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
         if (opt_l0_env) l0 = std::max(1, atoi(opt_l0_env));
         const int l0_safe = (int)(1.6 * total_tiles / kk);
         if (!opt_l0_env) l0 = std::min(l0, l0_safe);
+        // one round of workgroups where that still leaves 24 tiles (2214 queries: 9 x 28 = 252 <= 256; 9 x 29 needs a second
+        // round for 5 workgroups: 29 -> 51 us)
+        if (!opt_l0_env && wgs >= 24) l0 = std::min(l0, wgs);
         // (measured, 1M x 768, k = 100, same box, against the sample levels: 512 queries 1.02 -> 0.91 ms, 1024: 1.80 -> 1.62,
         // 2214: 3.79 -> 3.60, 4096: 6.59 -> 6.27; below 24 sample tiles -- small corpora, large k -- the levels stay)
         if ((l0 >= 24 || opt_l0_env) && l0 <= total_tiles / 8 && (long long)l0 * S16_BM >= 4ll * opt_rank && opt_rank <= kk) {
