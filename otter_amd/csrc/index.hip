@@ -3388,7 +3388,9 @@ int run_merge(otter_index* ix, const u64* in, const u32* in_cnt, int cap_in, int
     // workgroups share a CU (measured: 1 ... 256 queries 1024 threads, 2214 queries 256 threads); a pool that
     // takes every strip at once needs one select round
     if (nq < 1024 && k + take <= MAX_SELECT) return launch_merge<1024, MAX_SELECT>(ix->device, ma, nq, st);
-    if (all_in > 4096 && all_in <= MAX_SELECT && !(mv && mv[0] == 'd')) return launch_merge<512, MAX_SELECT>(ix->device, ma, nq, st);
+    // (a pool that takes every strip at once needs one select round, but its 68 KiB of LDS leave two workgroups per CU:
+    // measured at 2214 queries x 28 strips, round 3: 0.096 -> 0.060 ms with the 4096-entry pool; kept behind 'e' for A/B runs)
+    if (all_in > 4096 && all_in <= MAX_SELECT && mv && mv[0] == 'e') return launch_merge<512, MAX_SELECT>(ix->device, ma, nq, st);
     if (k + take <= 4096) return launch_merge<256, 4096>(ix->device, ma, nq, st);
     if (k + take > MAX_SELECT)
         return set_err(OTTER_EINVAL, "merge: k=%d + %d entries per strip exceed the %d-entry pool", k, take, MAX_SELECT);
