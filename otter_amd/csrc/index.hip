@@ -3849,7 +3849,7 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
     }
 #ifdef SCAN_DIAG
     // ablation: an unreachable threshold (no appends in the main scan; results are garbage)
-    if (getenv("OTTER_DIAG_NOHIT") && sample) (void)hipMemsetAsync(ix->thr0.p, 0xFF, (size_t)nq_pad * 4, st);
+    if (getenv("OTTER_DIAG_NOHIT") && (sample || opt_l0)) (void)hipMemsetAsync(ix->thr0.p, 0xFF, (size_t)nq_pad * 4, st);
 #endif
     sa.skip_final = 0;
     sa.strips = strips;
