@@ -4108,7 +4108,9 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
                     if (*hw == 0xFFFFFFFFu) return set_err(OTTER_EHIP, "search: the finish kernel ended without its proof word");
                 }
             }
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#endif
         }
         nf = *hw;
     } else {
