@@ -340,3 +340,22 @@ def test_small_batch_finish_kernel_equals_the_four_launches(n, d, k, monkeypatch
     assert ix.last_fallback == 0
     ix.close()
     ref.close()
+
+
+def test_optimistic_sample_with_more_tiles_than_scan_strips():
+    """4,500 queries = 18 query tiles leave the scan 14 strips per tile, while the optimistic threshold samples 29 tiles:
+    the block-maxima launch must not touch the per-strip candidate counts (it once wrote 29 rows of a 14-row array).
+    Result = the exact kernels'."""
+    from otter_amd.index import IndexFlatIP
+    xb, q = _mk(300000, 128, 4500, seed=5)
+    ix = IndexFlatIP(128)
+    ix.add(xb)
+    D, I = ix.search(q, 10)
+    assert ix.last_fallback == 0
+    ref = IndexFlatIP(128, planes="none")
+    ref.add(xb)
+    Dr, Ir = ref.search(q, 10)
+    np.testing.assert_array_equal(I, Ir)
+    np.testing.assert_array_equal(D.view(np.uint32), Dr.view(np.uint32))
+    ix.close()
+    ref.close()
