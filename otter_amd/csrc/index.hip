@@ -534,7 +534,10 @@ struct StreamArgs {
 
 constexpr int ST_BM = 256, ST_SYNC_WORDS = 128;   // (see StreamArgs::sync)
 // stream64_kernel: thresholds of up to 64 queries at [2..65], claim counter at [67]; held tiles; LDS image of the queries
-constexpr int S64_CLAIM = 67, S64_HOLD = 3, S64_NQP = 64;
+#ifndef S64_HOLD_TILES
+#define S64_HOLD_TILES 3
+#endif
+constexpr int S64_CLAIM = 67, S64_HOLD = S64_HOLD_TILES, S64_NQP = 64;
 __host__ __device__ constexpr u32 s64_pitch(int ld) { return (u32)ld * 2u + (((ld / 64) & 1) ? 0u : 128u); }   // odd multiple of 128 B
 constexpr int st_qinstr(int G, int BK) { return (4 * G * BK * 4 + 1023) / 1024; }              // LDS-DMA instructions for the queries
 constexpr int st_slot(int G, int BK) { return 64 * BK * 4 + st_qinstr(G, BK) * 1024; }        // per wave and stage
