@@ -14,8 +14,8 @@ scripts/eval_ottqa_retrieval.py:110-112, scripts/encode_corpus.py:109-113); laun
 torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.  Every rank
 holds its own 1M-row shard of an N x 1M-row corpus (row-sharded, weak scaling) inside
 otter_amd.sharded.ShardedIndexFlatIP -- the class the gloo tests cover -- which searches the
-shard for all queries, exchanges the packed (id, score) candidates with ONE RCCL all-gather and
-merges them on the GPU.  `value` counts the 1M-row query scans all ranks complete per second
+shard for all queries, exchanges the packed candidates (8 bytes each: fp32 score + 32-bit shard-local row)
+with ONE RCCL all-gather and merges them on the GPU.  `value` counts the 1M-row query scans all ranks complete per second
 (N * 2214 per step), which at N = 1 is plain queries/s on configs[1].  The run fails if the
 process group that forms is not N ranks.
 
@@ -24,8 +24,8 @@ batches run the coarse pass of the exact search on the bf16 matrix cores (bf16 p
 operands), so the kernel's work per launch is nprod * 2*N*d*nq bf16 flops against the dense bf16
 MFMA peak; the fp32-equivalent rate 2*N*d*nq / t is printed beside it.  Time = HIP events around
 the kernel, taken inside the timed region by the library's timing hook on the launch stream.
-Untimed-by-`value` legs on rank 0 at N = 1: `small_batches` (nq = 1 / 8 / 32, the reference's
-real call pattern and the HBM-bound regime: scan ms, wall ms, GB/s against 8 TB/s), `pcie`
+Untimed-by-`value` legs on rank 0 at N = 1: `small_batches` (nq = 1 ... 256: the reference's
+real call pattern, the HBM-bound regime and the sizes just above it: scan ms, wall ms, GB/s against 8 TB/s), `pcie`
 (host numpy in / out of the same search), `dim2304` (the dimension the reference script uses,
 scripts/eval_ottqa_retrieval.py:74), `encode` (corpus-encode blocks/s, BASELINE.json configs[3]).
 `cpu_baseline` is oracle/flat_ip.py (numpy sgemm + k-select port of IndexFlatIP, one batched call)
@@ -622,7 +622,7 @@ def main():
                          "note": "same search with pageable host numpy buffers: H2D of %d x %d fp32 queries + D2H of "
                                  "(D, I) inside the call; never `value`" % (nq, d)}
 
-    exchange = None if world == 1 else "%s of packed (id, score) candidates, %d bytes sent per rank and step" % (
+    exchange = None if world == 1 else "%s of packed (score, shard-local row) candidates, %d bytes sent per rank and step" % (
         six.last_exchange, six.last_exchange_bytes)
     six.local.close()
     del index, six, check_rows
