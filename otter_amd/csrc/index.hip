@@ -2305,8 +2305,142 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     }
 }
 
+// The same gather with 64 candidates per wave and v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4 rows x 4 columns x ONE k: a
+// plain fma per output, lane l supplies row l, 8 cycles per k for 64 rows) instead of 32x32x2 with the query in all 32
+// columns (64 cycles per two k for 32 rows: per 2214 x 211 candidates the chain of dependent MFMAs alone was 0.17 ms of
+// matrix-pipe time in a 0.30 ms kernel).  Same k order (0,4,1,5,2,6,3,7 per 8), same bits (stream_kernel's instruction).
+template <bool QLDS>
+__global__ __launch_bounds__(512) void rescore64_kernel(RescoreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char rsm[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = (int)(blockDim.x >> 6);
+    const int q = blockIdx.x / a.wg_per_q, part = blockIdx.x - q * a.wg_per_q;
+    const float* qrow = a.Q + (size_t)q * a.ld;
+    char* wbuf = rsm + wave * 16384;                      // [2][64 rows][128 B]
+    float* sQ = reinterpret_cast<float*>(rsm + nw * 16384);
+    if (QLDS) {
+        for (int i = threadIdx.x; i < a.ld / 4; i += (int)blockDim.x)
+            reinterpret_cast<float4*>(sQ)[i] = reinterpret_cast<const float4*>(qrow)[i];
+        __syncthreads();
+    }
+    const int S = a.ld / 32;                              // steps of 32 floats (ld is a multiple of 64: S is even)
+    const int lr = lane >> 3, lc = lane & 7;              // this lane's row within an instruction's 8, its 16-byte chunk
+    for (int c0 = (part * nw + wave) * 64; c0 < a.kc; c0 += a.wg_per_q * nw * 64) {
+        const int ci = c0 + lane;
+        const long long id = ci < a.kc ? a.Ic[(size_t)q * a.kc + ci] : -1ll;
+        const long long row = id >= 0 ? id - a.id_base : 0;
+        // rows 8 i + lr (i = 0..7) are the ones this lane fetches: their ids sit in lanes 8 i + lr
+        const f32x4* src[8];
+        u32 wofs[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = 8 * i + lr;
+            const long long rr = __shfl(row, r);
+            src[i] = reinterpret_cast<const f32x4*>(a.X + (size_t)rr * a.ld) + lc;
+            wofs[i] = (u32)r * 128u + (u32)((lc ^ ((r >> 1) & 7)) << 4);
+        }
+        const u32 rofs = (u32)lane * 128u;
+        const u32 rswz = (u32)((lane >> 1) & 7);
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 preA[8], preB[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            preA[i] = src[i][0];
+            preB[i] = src[i][8];                          // (step s: + 8 s float4 = 128 bytes per step)
+        }
+        auto step = [&](int s2, f32x4 (&pre)[8], char* buf) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(buf + wofs[i]) = pre[i];
+            if (s2 + 2 < S) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pre[i] = src[i][8 * (s2 + 2)];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 x0 = *reinterpret_cast<const float4*>(buf + rofs + ((((u32)(2 * j)) ^ rswz) << 4));
+                const float4 x1 = *reinterpret_cast<const float4*>(buf + rofs + ((((u32)(2 * j + 1)) ^ rswz) << 4));
+                const float4 q0 = QLDS ? *reinterpret_cast<const float4*>(sQ + 32 * s2 + 8 * j)
+                                       : *reinterpret_cast<const float4*>(qrow + 32 * s2 + 8 * j);
+                const float4 q1 = QLDS ? *reinterpret_cast<const float4*>(sQ + 32 * s2 + 8 * j + 4)
+                                       : *reinterpret_cast<const float4*>(qrow + 32 * s2 + 8 * j + 4);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(x0.x, q0.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(x1.x, q1.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(x0.y, q0.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(x1.y, q1.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(x0.z, q0.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(x1.z, q1.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(x0.w, q0.w, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(x1.w, q1.w, acc, 0, 0, 0);
+            }
+        };
+        for (int s2 = 0; s2 < S; s2 += 2) {
+            step(s2, preA, wbuf);
+            step(s2 + 1, preB, wbuf + 8192);
+        }
+        // lane l holds rows 4 (l >> 2) + i (i = 0..3) for column l & 3; all columns are equal: column 0 publishes
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rt = 4 * (lane >> 2) + i;
+            const long long idr = __shfl(id, rt);                 // candidate rt is held by lane rt
+            const int cr = c0 + rt;
+            if ((lane & 3) == 0 && cr < a.kc) {
+                const int s = cr / a.k, slot = cr - s * a.k;
+                const u64 comp = idr >= 0 ? (((u64)f2key(acc[i]) << 32) | (u64)(0xFFFFFFFFu - (u32)(idr - a.id_base))) : 0ull;
+                a.out[((size_t)s * a.nq_pad + q) * a.k + slot] = comp;
+            }
+        }
+    }
+    if (a.zero_word && blockIdx.x == 0 && threadIdx.x == 0) *a.zero_word = 0u;
+    // counts: invalid candidates (id < 0) are the tail of the list (one wave counts with ballots)
+    if (wave == 0 && part == 0) {
+        int valid = 0;
+        for (int i0 = 0; i0 < a.kc; i0 += 64) {
+            const int i = i0 + lane;
+            valid += __popcll(__ballot(i < a.kc && a.Ic[(size_t)q * a.kc + i] >= 0));
+        }
+        const int S2 = (a.kc + a.k - 1) / a.k;
+        for (int s = lane; s < S2; s += 64) a.out_cnt[(size_t)s * a.nq_pad + q] = (u32)max(0, min(a.k, valid - s * a.k));
+    }
+}
+
+// 64-candidate groups over as few rounds as four waves allow (2 x 8 KiB of LDS per wave)
+void launch_rescore64(const RescoreArgs& ra, unsigned grid, hipStream_t st) {
+    const size_t qbytes = (size_t)ra.ld * 4;
+    const bool qlds = qbytes <= 32768;
+    const int max_w = 4;
+    const int groups = std::max(1, (ra.kc + 63) / 64);
+    RescoreArgs a2 = ra;
+    int nw;
+    if ((long long)grid * groups <= 1024) {
+        a2.wg_per_q = groups;        // few queries: a query's groups spread over as many CUs
+        nw = 1;
+    } else {
+        const int rounds = (groups + max_w - 1) / max_w;
+        a2.wg_per_q = 1;
+        nw = (groups + rounds - 1) / rounds;
+    }
+    const size_t lds = (size_t)nw * 16384 + (qlds ? qbytes : 0);
+    static bool attr_set[64][2] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev][qlds ? 1 : 0]) {
+        if (qlds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rescore64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384 + 32768);
+        else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rescore64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
+        attr_set[dev][qlds ? 1 : 0] = true;
+    }
+    if (qlds) hipLaunchKernelGGL(rescore64_kernel<true>, dim3(grid * a2.wg_per_q), dim3(64 * nw), lds, st, a2);
+    else hipLaunchKernelGGL(rescore64_kernel<false>, dim3(grid * a2.wg_per_q), dim3(64 * nw), lds, st, a2);
+}
+
 // up to 8 waves per query, one 32-candidate group each; the query row staged in LDS when it fits beside the buffers
 void launch_rescore(const RescoreArgs& ra, unsigned grid, hipStream_t st) {
+    {
+        const char* ev = getenv("OTTER_RESCORE32");       // A/B runs: the 32x32x2 form
+        if (!(ev && ev[0] == '1')) return launch_rescore64(ra, grid, st);
+    }
     // waves = 32-candidate groups spread evenly over as few rounds as the waves allow (10 groups: 2 rounds of 5);
     // at most 8 waves, and no more than leave room for the query row beside their buffers in 64 KiB of LDS
     const size_t qbytes = (size_t)ra.ld * 4;
