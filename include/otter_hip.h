@@ -24,8 +24,7 @@
  *     these exceptions, which also wait for it: otter_index_search on an
  *     OTTER_F32 index of 65,536 and more rows whose coarse-pass planes fit HBM
  *     (one 4-byte word per pass of the coarse search: how many queries still
- *     lack a proof; usually one pass.  Above 64 queries it is read back behind a
- *     stream synchronisation; up to 64 the last kernel of the call stores it into
+ *     lack a proof; usually one pass.  The last kernel of the pass stores it into
  *     pinned memory and the host polls it -- the call returns when the results
  *     are decided, the kernel's tail may still be retiring on the stream), otter_index_search_subset (validation of
  *     the id lists), otter_index_add when the allocation grows, and

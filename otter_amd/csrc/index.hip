@@ -2472,11 +2472,11 @@ void launch_rescore(const RescoreArgs& ra, unsigned grid, hipStream_t st) {
 __global__ void margin_check_kernel(const float* Dexact, const float* Dcoarse, const long long* Icoarse,
                                     const float* qnorm2, const u32* xnorm2_max, float rel, long long nq, int k, int kc,
                                     long long n, u32* flags, u32* nflag, const float* qres2,
-                                    const u32* xres2_max, const u32* opt_thr) {
+                                    const u32* xres2_max, const u32* opt_thr, u32* ticket, u32* host_word) {
     const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (q >= nq) return;
-    bool ok;
-    if (n <= kc) {
+    bool ok = true;
+    if (q >= nq) {
+    } else if (n <= kc) {
         ok = true;                                              // every row is a candidate
     } else {
         const float tc = Dcoarse[q * kc + kc - 1];             // n > kc: the coarse list is full
@@ -2492,8 +2492,22 @@ __global__ void margin_check_kernel(const float* Dexact, const float* Dcoarse, c
         // entry reaches the threshold
         if (opt_thr && f2key(tc) < opt_thr[q]) ok = false;
     }
-    flags[q] = ok ? 0u : 1u;
+    if (q < nq) flags[q] = ok ? 0u : 1u;
     if (!ok) atomicAdd(nflag, 1u);
+    if (!host_word) return;
+    // the last block to finish hands the count of unproven queries to the host, which polls this pinned word: no copy,
+    // no stream synchronisation (the ticket is left at zero)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const u32 t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const u32 nf = __hip_atomic_load(nflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(host_word, nf, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ---- small batches (at most 64 queries): re-scoring, final selection and proof in ONE launch ----
@@ -4149,6 +4163,40 @@ int split_kc(int k, int mode, int d) {
     return k + std::max(60, (int)std::ceil(k * std::max(1.0, 0.04 * sd)));   // mode 3: twice mode 2's bound
 }
 
+// The one host round trip of a coarse pass: the last kernel of the pass stores the count of unproven queries into a
+// pinned, host-coherent word (armed with a sentinel before the launch) and the host polls it -- no copy, no stream
+// synchronisation.  Every 4096 looks the stream is asked whether it has ended: a kernel that died must not hang the
+// caller.
+int arm_poll_word(otter_index* ix) {
+    if (!ix->h_poll) OTTER_HIP_TRY(hipHostMalloc((void**)&ix->h_poll, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    *(volatile u32*)ix->h_poll = 0xFFFFFFFFu;
+    return OTTER_OK;
+}
+int wait_poll_word(otter_index* ix, hipStream_t st, long long* out) {
+    volatile u32* hw = ix->h_poll;
+    for (unsigned spins = 1; *hw == 0xFFFFFFFFu; ++spins) {
+        if ((spins & 4095u) == 0u) {
+            const hipError_t e = hipStreamQuery(st);
+            if (e != hipErrorNotReady) {
+                if (e != hipSuccess) OTTER_HIP_TRY(e);
+                if (*hw == 0xFFFFFFFFu) return set_err(OTTER_EHIP, "search: the pass ended without its proof word");
+            }
+        }
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
+    *out = *hw;
+    return OTTER_OK;
+}
+int reserve_fin(otter_index* ix, hipStream_t st) {
+    const bool fresh = ix->fin.p == nullptr;
+    int rc = ix->fin.reserve(128 * sizeof(u32));
+    if (rc) return rc;
+    if (fresh) OTTER_HIP_TRY(hipMemsetAsync(ix->fin.p, 0, 128 * sizeof(u32), st));   // (kernels leave the counters at zero)
+    return OTTER_OK;
+}
+
 int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, float* D, long long* I, hipStream_t st,
                        int mode, bool first) {
     const int kc = split_kc(k, mode, ix->d);
@@ -4203,10 +4251,8 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
     const char* no_fin = getenv("OTTER_NO_FINISH");
     if (small && kc <= FIN_MAX_KC && (size_t)ix->ld * 4 <= 32768 && !(no_fin && no_fin[0] == '1')) {
         // small batch: re-scoring, final selection and proof in one launch, the proof word polled from pinned memory
-        const bool fresh = ix->fin.p == nullptr;
-        if ((rc = ix->fin.reserve(128 * sizeof(u32)))) return rc;
-        if (fresh) OTTER_HIP_TRY(hipMemsetAsync(ix->fin.p, 0, 128 * sizeof(u32), st));
-        if (!ix->h_poll) OTTER_HIP_TRY(hipHostMalloc((void**)&ix->h_poll, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        if ((rc = reserve_fin(ix, st))) return rc;
+        if ((rc = arm_poll_word(ix))) return rc;
         FinishArgs fa;
         fa.X = ix->x;
         fa.Q = q_in_place ? qd : (const float*)ix->qpad.p;
@@ -4237,25 +4283,9 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
                                       hipFuncAttributeMaxDynamicSharedMemorySize, FIN_STAGES * FIN_ROWS * FIN_PITCH + 32768);
             attr_set[ix->device] = true;
         }
-        volatile u32* hw = ix->h_poll;
-        *hw = 0xFFFFFFFFu;
         hipLaunchKernelGGL(finish_small_kernel, dim3((unsigned)(nq * fa.parts)), dim3(256), lds, st, fa);
         OTTER_HIP_TRY(hipGetLastError());
-        // the one host round trip of this pass: the kernel's last workgroup stores the count of unproven queries here
-        // (every 4096 looks the stream is asked whether it has ended: a kernel that died must not hang the caller)
-        for (unsigned spins = 1; *hw == 0xFFFFFFFFu; ++spins) {
-            if ((spins & 4095u) == 0u) {
-                const hipError_t e = hipStreamQuery(st);
-                if (e != hipErrorNotReady) {
-                    if (e != hipSuccess) OTTER_HIP_TRY(e);
-                    if (*hw == 0xFFFFFFFFu) return set_err(OTTER_EHIP, "search: the finish kernel ended without its proof word");
-                }
-            }
-#if defined(__x86_64__) || defined(__i386__)
-            __builtin_ia32_pause();
-#endif
-        }
-        nf = *hw;
+        if ((rc = wait_poll_word(ix, st, &nf))) return rc;
     } else {
         RescoreArgs ra;
         ra.X = ix->x;
@@ -4274,20 +4304,18 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
         if ((rc = run_merge(ix, (const u64*)ix->rs.p, (const u32*)ix->rscnt.p, k, S2, nq, nq_pad, k, true, D, I, nullptr,
                             nullptr, nullptr, nullptr, nullptr, st)))
             return rc;
+        if ((rc = reserve_fin(ix, st))) return rc;
+        if ((rc = arm_poll_word(ix))) return rc;
         hipLaunchKernelGGL(margin_check_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (const float*)D,
                            (const float*)ix->cD.p, (const long long*)ix->cI.p, (const float*)ix->qnorm2.p,
                            (const u32*)ix->xnmax.p, split_rel_eps(ix->d), nq, k, kc, ix->n, flags, flags + nq,
                            mode >= 2 ? (const float*)ix->qres2.p : (const float*)nullptr,
                            mode == 3 ? (const u32*)ix->xrmax.p : (const u32*)nullptr,
-                           optimistic ? (const u32*)ix->thr0.p : (const u32*)nullptr);
+                           optimistic ? (const u32*)ix->thr0.p : (const u32*)nullptr, (u32*)ix->fin.p + 127, ix->h_poll);
         OTTER_HIP_TRY(hipGetLastError());
-        // the one host round trip of this pass (4 bytes): how many queries are left without a proof.  The
-        // stream is synchronised here -- once per pass of a large-batch search (see include/otter_hip.h).
-        // (into pinned memory: a copy to a pageable word goes through a staging buffer and a second wait)
-        if (!ix->h_flag) OTTER_HIP_TRY(hipHostMalloc((void**)&ix->h_flag, 64, hipHostMallocDefault));
-        OTTER_HIP_TRY(hipMemcpyAsync(ix->h_flag, flags + nq, sizeof(u32), hipMemcpyDeviceToHost, st));
-        OTTER_HIP_TRY(hipStreamSynchronize(st));
-        nf = *ix->h_flag;
+        // the one host round trip of this pass: how many queries are left without a proof (see wait_poll_word; the call
+        // returns when the results are decided, the stream may still be retiring the kernel's tail)
+        if ((rc = wait_poll_word(ix, st, &nf))) return rc;
     }
     if (mode >= 2 && first) ix->last_refined += nf;
     // (a verdict on the corpus needs a batch worth the name: one hard query of a one-query call is not one.  Small
