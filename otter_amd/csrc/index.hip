@@ -3397,8 +3397,7 @@ struct otter_index {
     otter::DevBuf qs, qnorm2, cD, cI, rs, rscnt, flags, fb_q, fb_D, fb_I;
     otter::DevBuf qpad, cand, cnt, lvl[2], lvlcnt[2], smp, smpcnt, thr0, io_q, io_D, io_I, bmax, sync, hold, bmax16;
     bool sync_dirty = true;         // the stream kernel's counters are not known to be zero
-    u32* h_flag = nullptr;          // pinned word for the one read-back of a coarse pass
-    u32* h_poll = nullptr;          // pinned, host-coherent word the small-batch finish kernel stores its count into
+    u32* h_poll = nullptr;          // pinned, host-coherent word the last kernel of a coarse pass stores its count of unproven queries into
     otter::DevBuf fin;              // that kernel's counters (zero between launches)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
@@ -4782,7 +4781,6 @@ void otter_index_destroy(otter_index* ix) {
     ix->io_q.release();
     ix->io_D.release();
     ix->io_I.release();
-    if (ix->h_flag) (void)hipHostFree(ix->h_flag);
     if (ix->h_poll) (void)hipHostFree(ix->h_poll);
     ix->fin.release();
     if (ix->sh_worker) {
