@@ -1,0 +1,101 @@
+"""tools/fuzz_search.py [--seconds S] [--seed N] — randomized parity run of IndexFlatIP.search against the CPU oracle.
+
+Random corpus sizes, row lengths, batch sizes, k, plane settings, chunked adds and score distributions (gaussian,
+clustered, quantized = many exact ties, duplicated rows); every result must equal oracle/flat_ip.c in the kernels'
+summation order bit for bit (D and I).  One index serves a few batch sizes in a row, so state left behind by one
+call (counters, tickets, poll words) meets the next.  Prints one line per case; exit status 1 if any case differs.
+A measurement tool like the tests: the oracle is the checker here, never the path.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle import flat_ip  # noqa: E402
+from otter_amd.index import IndexFlatIP  # noqa: E402
+
+
+def log_uniform(rng, lo, hi):
+    return int(round(np.exp(rng.uniform(np.log(lo), np.log(hi + 1)))))
+
+
+def make_corpus(rng, n, d, kind):
+    if kind == "gauss":
+        x = rng.randn(n, d)
+    elif kind == "cluster":
+        c = rng.randn(max(1, n // 500 + 1), d) * 2.0
+        x = c[rng.randint(0, c.shape[0], size=n)] + 0.05 * rng.randn(n, d)
+    elif kind == "quant":
+        x = rng.randint(-2, 3, size=(n, d)).astype(np.float64) * 0.5       # few distinct scores: ties everywhere
+    elif kind == "dup":
+        base = rng.randn(max(1, n // 3), d)
+        x = base[rng.randint(0, base.shape[0], size=n)]
+    elif kind == "sorted":
+        x = rng.randn(n, d)
+        x = x[np.argsort(x[:, 0])]                                          # rows ordered along one axis
+    else:
+        raise ValueError(kind)
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--min-n", type=int, default=1, help="smallest corpus (large ones reach the coarse passes)")
+    ap.add_argument("--max-work", type=float, default=6e10, help="n * d * nq bound per case (oracle time)")
+    ap.add_argument("--cases", type=int, default=0, help="stop after this many corpora (0: by time only)")
+    args = ap.parse_args(argv)
+    rng = np.random.RandomState(args.seed)
+    t_end = time.time() + args.seconds
+    bad = 0
+    case = 0
+    while time.time() < t_end and bad < 5 and (args.cases <= 0 or case < args.cases):
+        case += 1
+        d = int(rng.choice([64, 100, 128, 256, 768, 768, 960, 1024, 2304, log_uniform(rng, 1, 1200)]))
+        n = log_uniform(rng, args.min_n, 1300000)
+        while n * d > 1.2e9 and n // 2 >= args.min_n:
+            n //= 2
+        kind = str(rng.choice(["gauss", "gauss", "cluster", "quant", "dup", "sorted"]))
+        planes = str(rng.choice(["all", "all", "hi", "none"]))
+        xb = make_corpus(rng, n, d, kind)
+        ix = IndexFlatIP(d, planes=planes)
+        for part in np.array_split(xb, int(rng.randint(1, 4))):
+            if part.shape[0]:
+                ix.add(part)
+        for rep in range(int(rng.randint(1, 5))):
+            nq = log_uniform(rng, 1, 700)
+            while n * d * nq > args.max_work and nq > 1:
+                nq //= 2
+            k = min(log_uniform(rng, 1, 1200), 2048)
+            q = rng.randn(nq, d).astype(np.float32)
+            if kind == "quant":
+                q = np.round(q * 2.0) * 0.5
+            if kind == "cluster" and rng.rand() < 0.5:
+                q[: max(1, nq // 2)] = xb[rng.randint(0, n, size=max(1, nq // 2))]     # queries that sit on a cluster
+            t0 = time.time()
+            D, I = ix.search(q, k)
+            t1 = time.time()
+            Dr, Ir = flat_ip.search_c(xb, q, k, mode=flat_ip.MODE_GPU_ORDER)
+            ok = np.array_equal(I, Ir) and np.array_equal(D.view(np.uint32), Dr.view(np.uint32))
+            print("case %4d.%d  n=%8d d=%5d nq=%4d k=%5d %-7s planes=%-4s  gpu %.3fs cpu %.2fs  %s  coarse_state=%s" % (
+                case, rep, n, d, nq, k, kind, planes, t1 - t0, time.time() - t1, "ok" if ok else "DIFFERENT",
+                ix.coarse_state), flush=True)
+            if not ok:
+                bad += 1
+                rows = np.nonzero((I != Ir).any(axis=1) | (D.view(np.uint32) != Dr.view(np.uint32)).any(axis=1))[0]
+                print("   seed=%d first differing queries %s" % (args.seed, rows[:8]), flush=True)
+                r = int(rows[0])
+                c = int(np.nonzero((I[r] != Ir[r]) | (D[r].view(np.uint32) != Dr[r].view(np.uint32)))[0][0])
+                print("   q %d col %d: got (%r, %d) want (%r, %d)" % (r, c, D[r, c], I[r, c], Dr[r, c], Ir[r, c]), flush=True)
+        ix.close()
+    print("cases: %d, different: %d" % (case, bad), flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
