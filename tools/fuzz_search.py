@@ -16,7 +16,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from oracle import flat_ip  # noqa: E402
-from otter_amd.index import IndexFlatIP  # noqa: E402
+from otter_amd.index import IndexFlatIP, MultiGpuIndexFlatIP  # noqa: E402
 
 
 def log_uniform(rng, lo, hi):
@@ -48,6 +48,8 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--min-n", type=int, default=1, help="smallest corpus (large ones reach the coarse passes)")
     ap.add_argument("--max-work", type=float, default=6e10, help="n * d * nq bound per case (oracle time)")
+    ap.add_argument("--sharded-prob", type=float, default=0.15,
+                    help="share of corpora held by MultiGpuIndexFlatIP (2 ... 4 shards, all on GPU 0)")
     ap.add_argument("--cases", type=int, default=0, help="stop after this many corpora (0: by time only)")
     args = ap.parse_args(argv)
     rng = np.random.RandomState(args.seed)
@@ -63,10 +65,16 @@ def main(argv=None):
         kind = str(rng.choice(["gauss", "gauss", "cluster", "quant", "dup", "sorted"]))
         planes = str(rng.choice(["all", "all", "hi", "none"]))
         xb = make_corpus(rng, n, d, kind)
-        ix = IndexFlatIP(d, planes=planes)
-        for part in np.array_split(xb, int(rng.randint(1, 4))):
-            if part.shape[0]:
-                ix.add(part)
+        shards = int(rng.randint(2, 5)) if rng.rand() < args.sharded_prob else 1
+        if shards > 1:
+            planes = "x%d" % shards
+            ix = MultiGpuIndexFlatIP(d, devices=[0] * shards)
+            ix.add(xb)
+        else:
+            ix = IndexFlatIP(d, planes=planes)
+            for part in np.array_split(xb, int(rng.randint(1, 4))):
+                if part.shape[0]:
+                    ix.add(part)
         for rep in range(int(rng.randint(1, 5))):
             nq = log_uniform(rng, 1, 700)
             while n * d * nq > args.max_work and nq > 1:
@@ -82,9 +90,16 @@ def main(argv=None):
             t1 = time.time()
             Dr, Ir = flat_ip.search_c(xb, q, k, mode=flat_ip.MODE_GPU_ORDER)
             ok = np.array_equal(I, Ir) and np.array_equal(D.view(np.uint32), Dr.view(np.uint32))
+            if shards == 1 and nq <= 32 and k <= 128 and d <= 4096 and n > 0:
+                # the allocation-free entry point (exact fp32 stream kernels) on the same queries
+                import torch
+                De = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+                Ie = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+                ix.search_noalloc(torch.from_numpy(q).cuda(), k, De, Ie)
+                ok = ok and np.array_equal(Ie.cpu().numpy(), Ir) and np.array_equal(De.cpu().numpy().view(np.uint32), Dr.view(np.uint32))
             print("case %4d.%d  n=%8d d=%5d nq=%4d k=%5d %-7s planes=%-4s  gpu %.3fs cpu %.2fs  %s  coarse_state=%s" % (
                 case, rep, n, d, nq, k, kind, planes, t1 - t0, time.time() - t1, "ok" if ok else "DIFFERENT",
-                ix.coarse_state), flush=True)
+                ix.coarse_state if shards == 1 else "-"), flush=True)
             if not ok:
                 bad += 1
                 rows = np.nonzero((I != Ir).any(axis=1) | (D.view(np.uint32) != Dr.view(np.uint32)).any(axis=1))[0]
