@@ -25,3 +25,12 @@ def test_random_shapes_match_the_oracle():
 def test_random_large_corpora_match_the_oracle():
     # corpora large enough for the coarse passes (bf16 planes, re-scoring, proof) and the optimistic start
     assert _fuzz().main(["--seed", "4", "--cases", "5", "--seconds", "100", "--min-n", "300000", "--max-work", "1e11"]) == 0
+
+
+def test_random_encoder_shapes_match_the_restatement():
+    # tools/fuzz_encoder.py: family, pooling, projection, class, batch, any sequence length <= 512, ragged rows; fp32
+    # path at the fixtures' tolerance against oracle/encoder_ref.py, bf16 path by cosine
+    spec = importlib.util.spec_from_file_location("fuzz_encoder", os.path.join(ROOT, "tools", "fuzz_encoder.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(["--seed", "2", "--cases", "80", "--seconds", "100"]) == 0
