@@ -2490,7 +2490,10 @@ __global__ void margin_check_kernel(const float* Dexact, const float* Dcoarse, c
         // the coarse scan started from an OPTIMISTIC threshold (a guess at the kc-th best score from a small sample):
         // rows whose key lies below it were never looked at, so the coarse list is the true top kc only if its last
         // entry reaches the threshold
-        if (opt_thr && f2key(tc) < opt_thr[q]) ok = false;
+        if (opt_thr && f2key(tc) < opt_thr[q]) {
+            ok = false;
+            if (ticket) atomicAdd(ticket - 1, 1u);       // counted apart: the guess failed, not the coarse score's bound
+        }
     }
     if (q < nq) flags[q] = ok ? 0u : 1u;
     if (!ok) atomicAdd(nflag, 1u);
@@ -2503,7 +2506,12 @@ __global__ void margin_check_kernel(const float* Dexact, const float* Dcoarse, c
         const u32 t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == gridDim.x - 1u) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const u32 nf = __hip_atomic_load(nflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u32 nf = __hip_atomic_load(nflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // bit 31: more than a quarter of the batch missed its optimistic threshold (the word before the ticket counts
+            // them; both are left at zero)
+            const u32 nopt = __hip_atomic_load(ticket - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned long long)nopt * 4ull > (unsigned long long)nq) nf |= 0x80000000u;
+            __hip_atomic_store(ticket - 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(host_word, nf, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -3389,6 +3397,7 @@ struct otter_index {
     otter::DevBuf xh, xres2, xrmax, qh16, fb3_q, fb3_D, fb3_I;
     long long xh_rows = 0, xh_cap = 0;
     bool xh_failed = false, one_prod_off = false;
+    bool opt_off = false;           // the optimistic start guessed too high for more than a quarter of a batch: sample levels until reset()
     int planes = 2;                 // otter_index_set_planes: 0 none, 1 the bf16 hi plane only, 2 all (hi + hi/lo)
     long long win_q[4] = {0, 0, 0, 0}, win_f[4] = {0, 0, 0, 0};   // small calls: queries seen / left unproven, per pass
     bool coarse_off = false;        // even the three-product pass left > 1/4 of a batch unproven (scores within rounding of each
@@ -4235,7 +4244,7 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
             rc = search_chunk_stream(ix, qd, nq, kc, (float*)ix->cD.p, (long long*)ix->cI.p, st, &own, ix->qh16.p, ix->xh.p);
         } else {
             // (measured, 1M x 768, one query tile: 65 queries 0.539 -> 0.507 ms, 256: 0.650 -> 0.616, 384: 1.06 -> 1.00)
-            optimistic = nq > S64_NQP;
+            optimistic = nq > S64_NQP && !ix->opt_off;
             rc = scan16_and_merge<0>(ix, ix->xh.p, ix->ld, nq, kc, (float*)ix->cD.p, (long long*)ix->cI.p, st, ix->qh16.p,
                                      &optimistic);
         }
@@ -4246,6 +4255,7 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
     if (rc) return rc;
     u32* flags = (u32*)ix->flags.p;
     long long nf = 0;
+    bool opt_missed = false;
     // (read per call: the tests compare the two forms)
     const char* no_fin = getenv("OTTER_NO_FINISH");
     if (small && kc <= FIN_MAX_KC && (size_t)ix->ld * 4 <= 32768 && !(no_fin && no_fin[0] == '1')) {
@@ -4315,12 +4325,23 @@ int search_chunk_split(otter_index* ix, const float* qd, long long nq, int k, fl
         // the one host round trip of this pass: how many queries are left without a proof (see wait_poll_word; the call
         // returns when the results are decided, the stream may still be retiring the kernel's tail)
         if ((rc = wait_poll_word(ix, st, &nf))) return rc;
+        if (nf & 0x80000000ll) {
+            // the optimistic thresholds were too high for more than a quarter of the batch (a corpus whose best rows sit
+            // where the spread sample looks: the guess is not a verdict on the one-product bound): this index goes back to
+            // the sample levels, the queries take the next pass as always
+            nf &= 0x7FFFFFFFll;
+            opt_missed = true;
+            if (!ix->opt_off)
+                fprintf(stderr, "[libotter_hip] note: the optimistic threshold of the coarse scan was too high for more than a "
+                                "quarter of %lld queries; this index uses the sample levels until reset()\n", nq);
+            ix->opt_off = true;
+        }
     }
     if (mode >= 2 && first) ix->last_refined += nf;
     // (a verdict on the corpus needs a batch worth the name: one hard query of a one-query call is not one.  Small
     // calls -- the reference issues ONE query per call -- are judged over a running window of 64 queries per pass,
     // so a corpus whose proofs fail stops paying for the coarse pass there too)
-    bool verdict = nq >= 32 && nf * 4 > nq;
+    bool verdict = nq >= 32 && nf * 4 > nq && !opt_missed;
     if (nq < 32 && first) {
         ix->win_q[mode] += nq;
         ix->win_f[mode] += nf;
@@ -4679,6 +4700,7 @@ int otter_index_reset(otter_index* ix) {
     ix->xs_rows = 0;
     ix->two_prod_off = false;
     ix->one_prod_off = false;
+    ix->opt_off = false;
     ix->coarse_off = false;
     for (int m = 0; m < 4; ++m) ix->win_q[m] = ix->win_f[m] = 0;
     ix->xh_rows = 0;

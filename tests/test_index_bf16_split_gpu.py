@@ -218,11 +218,13 @@ def test_one_query_calls_also_switch_the_coarse_pass_off():
     ix.close()
 
 
-def test_optimistic_threshold_failures_are_searched_again():
+def test_optimistic_threshold_failures_are_searched_again(capfd):
     """Large batches start their coarse scan from an optimistic threshold (the 12th best of a small sample) and verify
     afterwards.  Forced to fail here: rank 1 (the best sample score) is far above the true kc-th best, so nearly every
     query misses candidates, is flagged by the check and goes through the next pass -- the result must still be the
-    oracle's, bit for bit; with the default rank nothing is refined."""
+    oracle's, bit for bit; with the default rank nothing is refined.  A batch that misses its guesses for more than a
+    quarter of its queries says so once and sends the index back to the sample levels -- not to the two-product pass:
+    the guess failed, not the one-product bound -- where the same batch proves every query again."""
     import os
     from otter_amd.index import IndexFlatIP
     rng = np.random.RandomState(11)
@@ -246,6 +248,13 @@ def test_optimistic_threshold_failures_are_searched_again():
     assert refined > nq // 2, refined
     np.testing.assert_array_equal(I1, I0)
     np.testing.assert_array_equal(D1.view(np.uint32), D0.view(np.uint32))
+    assert "optimistic threshold" in capfd.readouterr().err
+    for _ in range(2):                         # sample levels from here on: same bits, nothing refined, no second note
+        D2, I2 = ix.search(q, k)
+        assert ix.last_refined == 0 and ix.last_fallback == 0
+        np.testing.assert_array_equal(I2, I0)
+        np.testing.assert_array_equal(D2.view(np.uint32), D0.view(np.uint32))
+    assert "optimistic threshold" not in capfd.readouterr().err
     ix.close()
 
 
