@@ -50,6 +50,8 @@ def main(argv=None):
     ap.add_argument("--max-work", type=float, default=6e10, help="n * d * nq bound per case (oracle time)")
     ap.add_argument("--sharded-prob", type=float, default=0.15,
                     help="share of corpora held by MultiGpuIndexFlatIP (2 ... 4 shards, all on GPU 0)")
+    ap.add_argument("--bf16-prob", type=float, default=0.15,
+                    help="share of corpora in a bf16-storage index (order-free check on the rounded operands)")
     ap.add_argument("--cases", type=int, default=0, help="stop after this many corpora (0: by time only)")
     args = ap.parse_args(argv)
     rng = np.random.RandomState(args.seed)
@@ -66,7 +68,12 @@ def main(argv=None):
         planes = str(rng.choice(["all", "all", "hi", "none"]))
         xb = make_corpus(rng, n, d, kind)
         shards = int(rng.randint(2, 5)) if rng.rand() < args.sharded_prob else 1
-        if shards > 1:
+        bf16 = shards == 1 and rng.rand() < args.bf16_prob
+        if bf16:
+            planes = "bf16"
+            ix = IndexFlatIP(d, dtype="bf16")
+            ix.add(xb)
+        elif shards > 1:
             planes = "x%d" % shards
             ix = MultiGpuIndexFlatIP(d, devices=[0] * shards)
             ix.add(xb)
@@ -88,9 +95,24 @@ def main(argv=None):
             t0 = time.time()
             D, I = ix.search(q, k)
             t1 = time.time()
-            Dr, Ir = flat_ip.search_c(xb, q, k, mode=flat_ip.MODE_GPU_ORDER)
-            ok = np.array_equal(I, Ir) and np.array_equal(D.view(np.uint32), Dr.view(np.uint32))
-            if shards == 1 and nq <= 32 and k <= 128 and d <= 4096 and n > 0:
+            if bf16:
+                # scores are exact products of bf16 values accumulated in fp32: the order-free rule on the rounded
+                # operands (float64 arbiter), on as many queries as the arbiter scores in a few seconds
+                import torch
+                m = max(1, min(nq, int(2e9 // max(1, n * d))))
+                xr = torch.from_numpy(xb).to(torch.bfloat16).float().numpy()
+                qr = torch.from_numpy(q[:m]).to(torch.bfloat16).float().numpy()
+                try:
+                    flat_ip.check_topk(xr, qr, D[:m], I[:m], k, rtol=1e-5)
+                    ok = True
+                except AssertionError as e:
+                    print("   check_topk: %s" % e, flush=True)
+                    ok = False
+                Dr, Ir = D, I
+            else:
+                Dr, Ir = flat_ip.search_c(xb, q, k, mode=flat_ip.MODE_GPU_ORDER)
+                ok = np.array_equal(I, Ir) and np.array_equal(D.view(np.uint32), Dr.view(np.uint32))
+            if not bf16 and shards == 1 and nq <= 32 and k <= 128 and d <= 4096 and n > 0:
                 # the allocation-free entry point (exact fp32 stream kernels) on the same queries
                 import torch
                 De = torch.empty((nq, k), dtype=torch.float32, device="cuda")
@@ -100,6 +122,9 @@ def main(argv=None):
             print("case %4d.%d  n=%8d d=%5d nq=%4d k=%5d %-7s planes=%-4s  gpu %.3fs cpu %.2fs  %s  coarse_state=%s" % (
                 case, rep, n, d, nq, k, kind, planes, t1 - t0, time.time() - t1, "ok" if ok else "DIFFERENT",
                 ix.coarse_state if shards == 1 else "-"), flush=True)
+            if not ok and bf16:
+                bad += 1
+                continue
             if not ok:
                 bad += 1
                 rows = np.nonzero((I != Ir).any(axis=1) | (D.view(np.uint32) != Dr.view(np.uint32)).any(axis=1))[0]
