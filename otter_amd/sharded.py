@@ -59,14 +59,14 @@ class PackedCandidates:
 
 def to_local_ids(I, base):
     """int64 global ids -> int32 indexes inside the shard starting at `base` (-1 stays -1)."""
-    return torch.where(I >= 0, I - int(base), I).to(torch.int32)
+    # (valid ids are >= base, the missing -1 falls to -1 - base: two elementwise kernels instead of four)
+    return (I - int(base)).clamp_(min=-1).to(torch.int32)
 
 
 def to_global_ids(I32, bases):
     """[G, rows, k] int32 shard-local indexes -> int64 global ids, bases[g] added to list g (-1 stays -1)."""
-    I = I32.to(torch.int64)
-    b = bases.to(I.device).view((-1,) + (1,) * (I.dim() - 1))
-    return torch.where(I >= 0, I + b, I)
+    b = bases.to(I32.device).view((-1,) + (1,) * (I32.dim() - 1))
+    return torch.where(I32 >= 0, I32 + b, -1)           # (int32 + int64 promotes: no separate widening pass)
 
 
 class ShardedIndexFlatIP:
