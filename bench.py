@@ -677,7 +677,7 @@ def main():
                          {1: 0, 2: 2, 3: 1}[nprod],
                          {1: "x_hi*q_hi", 2: "x_hi*q_hi + x_lo*q_hi", 3: "x_hi*q_hi + x_hi*q_lo + x_lo*q_hi"}[nprod]) +
                      "kernel_ms is one HIP-event bracket per search on the launch stream = %d dispatches of this kernel "
-                     "and what runs between them: with the optimistic start (2 dispatches) a block-maxima launch over ~29 "
+                     "and what runs between them: with the optimistic start (2 dispatches) a block-maxima launch over 28 ... 64 "
                      "sample tiles, the 5 us threshold kernel and ONE scan of every tile (sample tiles scored twice: "
                      "+0.7%% kernel flops, not counted); otherwise threshold-seeding sample levels, the merges between "
                      "them and the main scan.  rocprof: TotalDurationNs of scan16_kernel / steps + those kernels"

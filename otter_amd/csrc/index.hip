@@ -3300,17 +3300,34 @@ void launch_scan16_bmax(const Scan16Args& a, int grid, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
 }
 
-// one wave per query: the key of the rank-th best of its M <= 128 block maxima (0 = fewer than rank blocks)
+// one wave per query: the key of the rank-th best of its M <= 256 block maxima (0 = fewer than rank blocks)
+constexpr int BMAX_THR_MAX = 256;
 __global__ __launch_bounds__(64) void bmax_thr_kernel(const u32* __restrict__ bmax, int M, int rank, u32* __restrict__ thr) {
     const int q = blockIdx.x, lane = threadIdx.x;
-    u64 x[2];
+    u64 x[BMAX_THR_MAX / 64];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < BMAX_THR_MAX / 64; ++e) {
         const int i = e * 64 + lane;
         x[e] = i < M ? ((u64)bmax[(size_t)q * M + i] << 32) | 1ull : 0ull;
     }
-    const u32 T = M >= rank ? wave_kth_key<2>(x, rank) : 0u;
+    const u32 T = M >= rank ? wave_kth_key<BMAX_THR_MAX / 64>(x, rank) : 0u;
     if (lane == 0) thr[q] = T;
+}
+
+// smallest rank r with P(Poisson(mu) >= r) <= p: the sample of an optimistic start holds Poisson(mu) rows above the true
+// kk-th best score of the corpus (mu = kk n0 / N); a threshold at the sample's r-th best is too high only if it holds r
+int poisson_rank(double mu, double p) {
+    for (int r = 1; r <= 96; ++r) {
+        double term = std::exp(-mu);
+        for (int j = 1; j <= r; ++j) term *= mu / j;            // P(X = r)
+        double tail = 0.0;
+        for (int j = r; j < r + 100; ++j) {
+            tail += term;
+            term *= mu / (j + 1);
+        }
+        if (tail <= p) return r;
+    }
+    return 97;
 }
 
 // largest k the bf16-MFMA scan keeps per query (its compaction holds CAP / 64 composites per lane)
@@ -3891,7 +3908,7 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
         // while kk <= 1.6 N / n0 (k = 100 on a million rows: kk = 211, n0 = 7168 at 2214 queries; not k = 1000).
         opt_rank = opt_env ? std::max(1, atoi(opt_env)) : 12;
         int l0 = 32;            // (block maxima need no workgroup per strip of the main scan: any number of tiles)
-        if (opt_l0_env) l0 = std::min(32, std::max(1, atoi(opt_l0_env)));   // (bmax_thr_kernel holds 128 block maxima per query)
+        if (opt_l0_env) l0 = std::min(BMAX_THR_MAX / 4, std::max(1, atoi(opt_l0_env)));   // (bmax_thr_kernel's block maxima per query)
         const int l0_safe = (int)(1.6 * total_tiles / kk);
         if (!opt_l0_env) l0 = std::min(l0, l0_safe);
         // one round of workgroups where that still leaves 24 tiles (2214 queries: 9 x 28 = 252 <= 256; 9 x 29 needs a second
@@ -3901,6 +3918,25 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
         // 2214: 3.79 -> 3.60, 4096: 6.59 -> 6.27; below 24 sample tiles -- small corpora, large k -- the levels stay)
         if ((l0 >= 24 || opt_l0_env) && l0 <= total_tiles / 8 && (long long)l0 * S16_BM >= 4ll * opt_rank && opt_rank <= kk) {
             opt_l0 = l0;        // (no level: block maxima of l0 tiles spread over the corpus, then ONE scan of every tile)
+            // A row the scan passes costs 35 us per kk of them and query (2214 queries; the rank-r threshold passes about
+            // r / mu x kk rows, mu = kk n0 / N sample rows expected above the true bound): where the start applies, the
+            // sample grows while it is cheap -- every tile one round of workgroups holds (few query tiles), or a second
+            // round (2214 queries: 56 tiles) -- up to 64 tiles (256 block maxima) and mu <= 4, and the rank follows from
+            // mu at the same failure probability as rank 12 at mu = 1.6 (1.5e-7 per query): 56 tiles -> rank 16, 5.3 kk
+            // rows passed instead of 7.9.
+            static const char* grow_env = getenv("OTTER_OPT_GROW");       // "0": the one-round sample and rank 12
+            if (!opt_l0_env && !opt_env && !(grow_env && grow_env[0] == '0')) {
+                int want = wgs >= 48 ? wgs : wgs >= 24 ? 2 * wgs : l0;
+                want = std::min(std::min(want, BMAX_THR_MAX / 4), std::min((int)(4.0 * total_tiles / kk), total_tiles / 8));
+                if (want > l0) {
+                    const double mu = (double)kk * want * S16_BM / (double)ix->n;
+                    const int r = poisson_rank(mu, 1.5e-7);
+                    if (r <= kk && (long long)want * S16_BM >= 4ll * r && r / mu < 12.0 / 1.6) {
+                        opt_l0 = want;
+                        opt_rank = r;
+                    }
+                }
+            }
         } else {
             opt_rank = 0;
         }
