@@ -3926,7 +3926,7 @@ int scan16_and_merge(otter_index* ix, const void* Xk, int ldk, long long nq, int
             // rows passed instead of 7.9.
             static const char* grow_env = getenv("OTTER_OPT_GROW");       // "0": the one-round sample and rank 12
             if (!opt_l0_env && !opt_env && !(grow_env && grow_env[0] == '0')) {
-                int want = wgs >= 48 ? wgs : wgs >= 24 ? 2 * wgs : l0;
+                int want = wgs >= 48 ? wgs : wgs >= 24 ? 2 * wgs : 3 * wgs;      // (whole rounds of workgroups)
                 want = std::min(std::min(want, BMAX_THR_MAX / 4), std::min((int)(4.0 * total_tiles / kk), total_tiles / 8));
                 if (want > l0) {
                     const double mu = (double)kk * want * S16_BM / (double)ix->n;
